@@ -1,0 +1,238 @@
+// g1.hip.h -- BLS12-381 G1 group law on the device (y^2 = x^3 + 4 over Fp).
+//
+// Replaces what the reference obtains from blst_p1_add_or_double (reference src/curves.rs:79-85)
+// and blst_p1_mult (src/curves.rs:90-96) inside Polynomial::commit (src/polynomial.rs:207-212).
+// Accumulators are extended Jacobian "XYZZ" (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2; ZZ = 0 <=> infinity):
+// the mixed addition with an affine SRS point costs 8M + 2S and the exceptional cases
+// (accumulator at infinity, equal points, opposite points) are handled explicitly -- they do
+// occur (SRS[0] = G, repeated coefficients) and the output must be bit-exact, not probable.
+#pragma once
+#include "field.hip.h"
+
+namespace kzg {
+
+#define KZG_SB() __builtin_amdgcn_sched_barrier(0)
+
+struct Affine {  // Montgomery x, y;  (0, 0) encodes the point at infinity (it is not on the curve)
+    Fp x, y;
+    KZG_DEV bool is_inf() const {
+        u32 o = 0;
+#pragma unroll
+        for (int i = 0; i < 12; i++) o |= x.l[i] | y.l[i];
+        return o == 0;
+    }
+};
+
+struct XYZZ {
+    Fp X, Y, ZZ, ZZZ;
+    KZG_DEV static XYZZ inf() {
+        XYZZ r;
+        r.X = Fp::zero();
+        r.Y = Fp::zero();
+        r.ZZ = Fp::zero();
+        r.ZZZ = Fp::zero();
+        return r;
+    }
+    KZG_DEV bool is_inf() const { return ZZ.is_zero(); }
+};
+
+KZG_DEV XYZZ xyzz_from_affine(const Affine& p) {
+    XYZZ r;
+    if (p.is_inf()) return XYZZ::inf();
+    r.X = p.x;
+    r.Y = p.y;
+    r.ZZ = Fp::one();
+    r.ZZZ = Fp::one();
+    return r;
+}
+
+// 2 * a (dbl-2008-s-1), fully unrolled: for kernels whose main operation is doubling.
+KZG_DEV XYZZ xyzz_dbl(const XYZZ& a) {
+    if (a.is_inf() || a.Y.is_zero()) return XYZZ::inf();
+    XYZZ r;
+    Fp U = fe_dbl(a.Y);
+    Fp V = fe_sqr(U);
+    KZG_SB();
+    Fp W = fe_mul(U, V);
+    KZG_SB();
+    Fp S = fe_mul(a.X, V);
+    KZG_SB();
+    r.ZZ = fe_mul(V, a.ZZ);
+    KZG_SB();
+    Fp M = fe_sqr(a.X);
+    KZG_SB();
+    M = fe_add(fe_dbl(M), M);
+    r.X = fe_sub(fe_sub(fe_sqr(M), S), S);
+    KZG_SB();
+    r.ZZZ = fe_mul(W, a.ZZZ);
+    KZG_SB();
+    Fp WY = fe_mul(W, a.Y);
+    KZG_SB();
+    r.Y = fe_sub(fe_mul(M, fe_sub(S, r.X)), WY);
+    KZG_SB();
+    return r;
+}
+
+// 2 * a on the rolled routines (exceptional branch of the additions: equal operands).
+// io = {X, Y, ZZ, ZZZ} as 4 x 12 words in private memory, overwritten with the double.
+__device__ __noinline__ void xyzz_dbl_rare(u32* io) {
+    u32 *X = io, *Y = io + 12, *ZZ = io + 24, *ZZZ = io + 36;
+    u32 U[12], V[12], W[12], S[12], M[12], T[12];
+    fp_rolled_add(U, Y, Y);
+    fp_rolled_mul(V, U, U);
+    fp_rolled_mul(W, U, V);
+    fp_rolled_mul(S, X, V);
+    fp_rolled_mul(M, X, X);
+    fp_rolled_add(T, M, M);
+    fp_rolled_add(M, T, M);
+    fp_rolled_mul(T, M, M);
+    fp_rolled_sub(T, T, S);
+    fp_rolled_sub(T, T, S);  // X3
+    fp_rolled_mul(ZZ, V, ZZ);
+    fp_rolled_mul(ZZZ, W, ZZZ);
+    fp_rolled_mul(W, W, Y);  // W * Y1
+    fp_rolled_sub(S, S, T);
+    fp_rolled_mul(S, M, S);
+    fp_rolled_sub(Y, S, W);
+#pragma unroll 1
+    for (int i = 0; i < 12; i++) X[i] = T[i];
+}
+
+// acc = 2 * acc through the rare path (caller has already excluded infinity / Y = 0 handled here)
+KZG_DEV void xyzz_dbl_inplace_rare(XYZZ& acc) {
+    if (acc.is_inf() || acc.Y.is_zero()) {
+        acc = XYZZ::inf();
+        return;
+    }
+    u32 io[48];
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        io[i] = acc.X.l[i];
+        io[12 + i] = acc.Y.l[i];
+        io[24 + i] = acc.ZZ.l[i];
+        io[36 + i] = acc.ZZZ.l[i];
+    }
+    xyzz_dbl_rare(io);
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        acc.X.l[i] = io[i];
+        acc.Y.l[i] = io[12 + i];
+        acc.ZZ.l[i] = io[24 + i];
+        acc.ZZZ.l[i] = io[36 + i];
+    }
+}
+
+// acc += p (affine), p negated when `neg`.  madd-2008-s with complete exceptional handling.
+// Statement order and the scheduling barriers keep at most ~8 field elements live (the compiler
+// otherwise interleaves the ten independent-looking products and spills).
+KZG_DEV void xyzz_madd(XYZZ& acc, const Affine& p_in, bool neg) {
+    if (p_in.is_inf()) return;
+    Fp py = neg ? fe_neg(p_in.y) : p_in.y;
+    if (acc.is_inf()) {
+        acc.X = p_in.x;
+        acc.Y = py;
+        acc.ZZ = Fp::one();
+        acc.ZZZ = Fp::one();
+        return;
+    }
+    Fp P = fe_sub(fe_mul(p_in.x, acc.ZZ), acc.X);  // U2 - X1
+    KZG_SB();
+    Fp R = fe_sub(fe_mul(py, acc.ZZZ), acc.Y);  // S2 - Y1
+    KZG_SB();
+    if (P.is_zero()) {
+        if (R.is_zero()) {
+            xyzz_dbl_inplace_rare(acc);  // acc == p as group elements: 2*acc
+        } else {
+            acc = XYZZ::inf();
+        }
+        return;
+    }
+    Fp PP = fe_sqr(P);
+    KZG_SB();
+    acc.ZZ = fe_mul(acc.ZZ, PP);
+    KZG_SB();
+    Fp Q = fe_mul(acc.X, PP);
+    KZG_SB();
+    Fp PPP = fe_mul(P, PP);
+    KZG_SB();
+    acc.ZZZ = fe_mul(acc.ZZZ, PPP);
+    KZG_SB();
+    Fp YP = fe_mul(acc.Y, PPP);
+    KZG_SB();
+    Fp X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    KZG_SB();
+    acc.Y = fe_sub(fe_mul(R, fe_sub(Q, X3)), YP);
+    acc.X = X3;
+    KZG_SB();
+}
+
+// acc += b : add-2008-s with complete exceptional handling.
+KZG_DEV void xyzz_add(XYZZ& acc, const XYZZ& b) {
+    if (b.is_inf()) return;
+    if (acc.is_inf()) {
+        acc = b;
+        return;
+    }
+    Fp U1 = fe_mul(acc.X, b.ZZ);
+    KZG_SB();
+    Fp P = fe_sub(fe_mul(b.X, acc.ZZ), U1);
+    KZG_SB();
+    Fp S1 = fe_mul(acc.Y, b.ZZZ);
+    KZG_SB();
+    Fp R = fe_sub(fe_mul(b.Y, acc.ZZZ), S1);
+    KZG_SB();
+    if (P.is_zero()) {
+        if (R.is_zero()) {
+            xyzz_dbl_inplace_rare(acc);
+        } else {
+            acc = XYZZ::inf();
+        }
+        return;
+    }
+    Fp PP = fe_sqr(P);
+    KZG_SB();
+    acc.ZZ = fe_mul(fe_mul(acc.ZZ, b.ZZ), PP);
+    KZG_SB();
+    Fp Q = fe_mul(U1, PP);
+    KZG_SB();
+    Fp PPP = fe_mul(P, PP);
+    KZG_SB();
+    acc.ZZZ = fe_mul(fe_mul(acc.ZZZ, b.ZZZ), PPP);
+    KZG_SB();
+    Fp YP = fe_mul(S1, PPP);
+    KZG_SB();
+    Fp X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    KZG_SB();
+    acc.Y = fe_sub(fe_mul(R, fe_sub(Q, X3)), YP);
+    acc.X = X3;
+    KZG_SB();
+}
+
+// Jacobian (X, Y, Z) as stored in blst_p1 -> XYZZ (no inversion): ZZ = Z^2, ZZZ = Z^3.
+KZG_DEV XYZZ xyzz_from_jacobian(const Fp& X, const Fp& Y, const Fp& Z) {
+    XYZZ r;
+    if (Z.is_zero()) return XYZZ::inf();
+    r.X = X;
+    r.Y = Y;
+    r.ZZ = fe_sqr(Z);
+    r.ZZZ = fe_mul(r.ZZ, Z);
+    return r;
+}
+
+// XYZZ -> Jacobian with Z' = ZZ*ZZZ... not needed: with the hidden z (ZZ = z^2, ZZZ = z^3),
+// (X*ZZ, Y*ZZZ, ZZ... ) is NOT Jacobian; use: Z' = ZZZ/ZZ is unavailable without inversion, so take
+// Z' = ZZ * ZZZ = z^5:  X' = x z'^2 = X * ZZ^4 ... cheaper: Z' = ZZ (= z^2): X' = x*ZZ^2 = X*ZZ,
+// Y' = y*ZZ^3 = Y*ZZZ.  Three multiplications, no inversion.
+KZG_DEV void xyzz_to_jacobian(const XYZZ& a, Fp& X, Fp& Y, Fp& Z) {
+    if (a.is_inf()) {
+        X = Fp::zero();
+        Y = Fp::zero();
+        Z = Fp::zero();
+        return;
+    }
+    X = fe_mul(a.X, a.ZZ);
+    Y = fe_mul(a.Y, a.ZZZ);
+    Z = a.ZZ;
+}
+
+}  // namespace kzg

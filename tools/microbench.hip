@@ -1,0 +1,336 @@
+// microbench.hip -- gfx950 integer-VALU ceilings for the field arithmetic (not part of the library).
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench tools/microbench.hip
+// Prints one JSON object per measurement.  The v_mad_u64_u32 issue rate measured here is the VALU
+// peak the MSM kernels are quoted against ("must be measured on the box").
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "../kzg_poly_commit_exploration_amd/csrc/g1.hip.h"
+
+using namespace kzg;
+
+#define CHECK(x)                                                                  \
+    do {                                                                          \
+        hipError_t e = (x);                                                       \
+        if (e != hipSuccess) {                                                    \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); \
+            exit(1);                                                              \
+        }                                                                         \
+    } while (0)
+
+constexpr int CHAINS = 8;
+
+__global__ void __launch_bounds__(256) k_mad(u64* out, int iters) {
+    u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 77u;
+    u64 acc[CHAINS];
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) acc[k] = a + k;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int k = 0; k < CHAINS; k++) acc[k] = mad64((u32)acc[k] ^ a, b + k, acc[k] >> 32);
+        }
+    }
+    u64 s = 0;
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) s ^= acc[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_mullo(u64* out, int iters) {
+    u32 a = threadIdx.x * 2654435761u + 12345u;
+    u32 acc[CHAINS];
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) acc[k] = a + k;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int k = 0; k < CHAINS; k++) acc[k] = acc[k] * (a | 1u);
+        }
+    }
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) s ^= acc[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_mulhi(u64* out, int iters) {
+    u32 a = threadIdx.x * 2654435761u + 12345u;
+    u32 acc[CHAINS];
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) acc[k] = a + k * 0x9e3779b9u;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int k = 0; k < CHAINS; k++) acc[k] = __umulhi(acc[k] | 0x80000000u, a | 0xC0000000u) + k;
+        }
+    }
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) s ^= acc[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_mad24(u64* out, int iters) {
+    u32 a = (threadIdx.x * 2654435761u + 12345u) & 0xffffffu;
+    u32 acc[CHAINS];
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) acc[k] = a + k;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int k = 0; k < CHAINS; k++) acc[k] = __umul24(acc[k], a) + (acc[k] >> 3);
+        }
+    }
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) s ^= acc[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_addc(u64* out, int iters) {
+    u32 a = threadIdx.x * 2654435761u + 12345u;
+    u32 acc[12], b[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+        acc[k] = a + k;
+        b[k] = a * (k + 3);
+    }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            u32 c = 0;
+#pragma unroll
+            for (int k = 0; k < 12; k++) acc[k] = addc(acc[k], b[k], c);
+            b[0] += c;
+        }
+    }
+    u32 s = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) s ^= acc[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(256) k_dfma(u64* out, int iters) {
+    double a = 1.0 + threadIdx.x * 1e-9, b = 0.999999;
+    double acc[CHAINS];
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) acc[k] = a + k;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int k = 0; k < CHAINS; k++) acc[k] = __fma_rn(acc[k], b, a);
+        }
+    }
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) s += acc[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (u64)s;
+}
+
+__global__ void __launch_bounds__(256) k_fpmul(u32* io, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x, y;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        x.l[i] = io[i];
+        y.l[i] = io[12 + i];
+    }
+    x.l[0] ^= (tid & 0xff);  // still < p (top limb untouched)
+    for (int it = 0; it < iters; it++) {
+        x = fe_mul(x, y);
+        y = fe_mul(y, x);
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            io[24 + i] = x.l[i];
+            io[36 + i] = y.l[i];
+        }
+    }
+    if (x.l[3] == 0x12345 && y.l[2] == 77) io[48] = 1;  // keep live for all threads
+}
+
+__global__ void __launch_bounds__(256) k_frmul(u32* io, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fr x, y;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        x.l[i] = io[i];
+        y.l[i] = io[8 + i];
+    }
+    x.l[0] ^= (tid & 0xff);
+    for (int it = 0; it < iters; it++) {
+        x = fe_mul(x, y);
+        y = fe_mul(y, x);
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            io[16 + i] = x.l[i];
+            io[24 + i] = y.l[i];
+        }
+    }
+    if (x.l[3] == 0x12345 && y.l[2] == 77) io[48] = 1;
+}
+
+__global__ void __launch_bounds__(256) k_madd(u32* io, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Affine p;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        p.x.l[i] = io[i];
+        p.y.l[i] = io[12 + i];
+    }
+    XYZZ acc = XYZZ::inf();
+    Affine q = p;
+    xyzz_madd(acc, p, false);
+    xyzz_madd(acc, p, false);  // acc = 2P (exercises the rare doubling path) so that acc != +-P below
+    for (int it = 0; it < iters; it++) {
+        xyzz_madd(acc, q, (it + tid) & 1);
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            io[24 + i] = acc.X.l[i];
+            io[36 + i] = acc.Y.l[i];
+            io[48 + i] = acc.ZZ.l[i];
+            io[60 + i] = acc.ZZZ.l[i];
+        }
+    }
+    if (acc.X.l[3] == 0x12345 && acc.Y.l[2] == 77) io[80] = 1;
+}
+
+template <class K, class... A>
+static double time_kernel(K kern, int grid, int block, int reps, A... args) {
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, args...);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int r = 0; r < reps; r++) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, args...);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+static void hexout(const char* name, const u32* l, int n) {
+    printf("\"%s\": \"", name);
+    for (int i = n - 1; i >= 0; i--) printf("%08x", l[i]);
+    printf("\"");
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    int cus = prop.multiProcessorCount;
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %d}\n", prop.gcnArchName, cus, prop.clockRate / 1000);
+    u64* out;
+    CHECK(hipMalloc(&out, sizeof(u64) * 256 * 8 * 1024));
+    const int block = 256;
+    const int iters = 2000;
+    for (int wps = 1; wps <= 4; wps *= 2) {  // waves per SIMD
+        int grid = cus * wps;
+        double n_inst = (double)grid * block * iters * 8 * CHAINS;
+        double ms;
+        ms = time_kernel(k_mad, grid, block, 5, out, iters);
+        printf("{\"bench\": \"v_mad_u64_u32\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gop_s\": %.1f}\n", wps, ms, n_inst / ms / 1e6);
+        ms = time_kernel(k_mullo, grid, block, 5, out, iters);
+        printf("{\"bench\": \"v_mul_lo_u32\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gop_s\": %.1f}\n", wps, ms, n_inst / ms / 1e6);
+        ms = time_kernel(k_mulhi, grid, block, 5, out, iters);
+        printf("{\"bench\": \"v_mul_hi_u32(+add)\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gop_s\": %.1f}\n", wps, ms, n_inst / ms / 1e6);
+        ms = time_kernel(k_mad24, grid, block, 5, out, iters);
+        printf("{\"bench\": \"v_mul_u32_u24(+shift+add)\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gop_s\": %.1f}\n", wps, ms, n_inst / ms / 1e6);
+        ms = time_kernel(k_dfma, grid, block, 5, out, iters);
+        printf("{\"bench\": \"v_fma_f64\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gop_s\": %.1f}\n", wps, ms, n_inst / ms / 1e6);
+        double n_add = (double)grid * block * iters * 8 * 12;
+        ms = time_kernel(k_addc, grid, block, 5, out, iters);
+        printf("{\"bench\": \"v_addc_co_u32 chain\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gop_s\": %.1f}\n", wps, ms, n_add / ms / 1e6);
+    }
+
+    // field-level
+    u32 h[128];
+    memset(h, 0, sizeof h);
+    // x = Gx (Montgomery), y = Gy (Montgomery)
+    const u32 GX[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
+                        0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
+    const u32 GY[12] = {0x0ce72271u, 0xbaac93d5u, 0x7918fd8eu, 0x8c22631au, 0x570725ceu, 0xdd595f13u,
+                        0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
+    u32* dio;
+    CHECK(hipMalloc(&dio, sizeof h));
+    for (int wps = 1; wps <= 4; wps *= 2) {
+        int grid = cus * wps;
+        const int fit = 200;
+        memcpy(h, GX, 48);
+        memcpy(h + 12, GY, 48);
+        CHECK(hipMemcpy(dio, h, sizeof h, hipMemcpyHostToDevice));
+        double ms = time_kernel(k_fpmul, grid, block, 3, dio, fit);
+        double nmul = (double)grid * block * fit * 2;
+        printf("{\"bench\": \"fp_mul\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gmul_s\": %.2f}\n", wps, ms, nmul / ms / 1e6);
+        ms = time_kernel(k_frmul, grid, block, 3, dio, fit);
+        printf("{\"bench\": \"fr_mul\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gmul_s\": %.2f}\n", wps, ms, nmul / ms / 1e6);
+        CHECK(hipMemcpy(dio, h, sizeof h, hipMemcpyHostToDevice));
+        const int mit = 64;
+        ms = time_kernel(k_madd, grid, block, 3, dio, mit);
+        double nadd = (double)grid * block * mit;
+        printf("{\"bench\": \"xyzz_madd\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gadd_s\": %.3f}\n", wps, ms, nadd / ms / 1e6);
+    }
+    // correctness probes (checked offline against Python big ints): 3 iterations of the fpmul loop
+    memcpy(h, GX, 48);
+    memcpy(h + 12, GY, 48);
+    CHECK(hipMemcpy(dio, h, sizeof h, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_fpmul, dim3(1), dim3(64), 0, 0, dio, 3);
+    CHECK(hipMemcpy(h, dio, sizeof h, hipMemcpyDeviceToHost));
+    printf("{\"probe\": \"fpmul3\", ");
+    hexout("x", h + 24, 12);
+    printf(", ");
+    hexout("y", h + 36, 12);
+    printf("}\n");
+    memset(h, 0, sizeof h);
+    memcpy(h, GX, 32);
+    memcpy(h + 8, GY, 32);
+    h[7] &= 0x3fffffffu;
+    h[15] &= 0x3fffffffu;
+    u32 hin[16];
+    memcpy(hin, h, 64);
+    CHECK(hipMemcpy(dio, h, sizeof h, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_frmul, dim3(1), dim3(64), 0, 0, dio, 3);
+    CHECK(hipMemcpy(h, dio, sizeof h, hipMemcpyDeviceToHost));
+    printf("{\"probe\": \"frmul3\", ");
+    hexout("x0", hin, 8);
+    printf(", ");
+    hexout("y0", hin + 8, 8);
+    printf(", ");
+    hexout("x", h + 16, 8);
+    printf(", ");
+    hexout("y", h + 24, 8);
+    printf("}\n");
+    memset(h, 0, sizeof h);
+    memcpy(h, GX, 48);
+    memcpy(h + 12, GY, 48);
+    CHECK(hipMemcpy(dio, h, sizeof h, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_madd, dim3(1), dim3(64), 0, 0, dio, 5);
+    CHECK(hipMemcpy(h, dio, sizeof h, hipMemcpyDeviceToHost));
+    printf("{\"probe\": \"madd5\", ");
+    hexout("X", h + 24, 12);
+    printf(", ");
+    hexout("Y", h + 36, 12);
+    printf(", ");
+    hexout("ZZ", h + 48, 12);
+    printf(", ");
+    hexout("ZZZ", h + 60, 12);
+    printf("}\n");
+    return 0;
+}
