@@ -1,0 +1,165 @@
+/* kzg_mi355x.h -- C-ABI of libkzg_mi355x.so: the MI355X (gfx950) engine behind the hot path of
+ * VGLoic/kzg-poly-commit-exploration, i.e. Polynomial::commit and Evaluation::generate_proof.
+ *
+ * The reference has no FFI seam of its own: commit / generate_proof are inherent Rust methods that
+ * descend into blst one scalar multiplication at a time (reference src/polynomial.rs:200-215,
+ * 260-269 -> src/curves.rs:79-96).  The boundary is therefore the BODY of those two methods; every
+ * entry point below cites the reference code it replaces, and INTEGRATION.md shows the Rust
+ * `extern "C"` block and the two method bodies a maintainer would write against this header.
+ *
+ * Layouts are blst's, so Rust passes its own memory without conversion:
+ *   Fr  ("blst_fr",  reference src/scalar.rs:7-8)   : 4 x uint64 little-endian limbs, Montgomery, R = 2^256
+ *   Fp  ("blst_fp")                                 : 6 x uint64 little-endian limbs, Montgomery, R = 2^384
+ *   G1  ("blst_p1",  reference src/curves.rs:10-17) : {x, y, z} Jacobian, 18 x uint64; z == 0 <=> infinity
+ *
+ * Conventions: plain pointers and sizes only; the caller owns every buffer; the library copies what
+ * it keeps and never retains a host pointer past return; every function returns 0 (KZG_OK) or a
+ * negative kzg_status; nothing throws or longjmps across the boundary.  One kzg_ctx drives one GPU
+ * (one process per GPU; see bench.py for the RCCL exchange); calls on one context are serialised
+ * internally, different contexts are independent.
+ *
+ * There is no CPU fallback: without a HIP device kzg_ctx_create fails with KZG_ERR_NO_DEVICE.
+ */
+#ifndef KZG_MI355X_H
+#define KZG_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kzg_ctx kzg_ctx;
+
+typedef enum kzg_status {
+    KZG_OK = 0,
+    /* "Setup does not allow for commitment generation of the polynomial. The polynomial degree is
+     * too high."  (reference src/polynomial.rs:201-205) */
+    KZG_ERR_DEGREE_TOO_HIGH = -1,
+    /* "Unable to divide a constant polynomial"  (reference src/polynomial.rs:159-167) */
+    KZG_ERR_CONSTANT_POLY = -2,
+    /* "[divide_by_root] Fail to divide the polynomial by a root, constant terms do not add up"
+     * (reference src/polynomial.rs:184-192) */
+    KZG_ERR_REMAINDER = -3,
+    KZG_ERR_INVALID_ARG = -4,
+    KZG_ERR_NO_DEVICE = -5,  /* no usable HIP device: the library has no CPU path */
+    KZG_ERR_HIP = -6,        /* a HIP runtime call failed; kzg_last_error() has the text */
+    KZG_ERR_NO_SRS = -7,     /* commit/open before kzg_srs_load_g1 / kzg_srs_generate_g1 */
+    KZG_ERR_BUSY = -8        /* async slot still in flight */
+} kzg_status;
+
+/* ---- context ------------------------------------------------------------------------------ */
+
+/* Creates the engine on HIP device `device` (streams, workspaces are sized at SRS load).
+ * No reference analogue: the reference is stateless and receives the SRS slice on every call
+ * (src/polynomial.rs:200); the context exists to keep the SRS resident in HBM. */
+int kzg_ctx_create(int device, kzg_ctx** out);
+void kzg_ctx_destroy(kzg_ctx* ctx);
+const char* kzg_strerror(int status);
+/* text of the last KZG_ERR_HIP on this context (valid until the next call on it) */
+const char* kzg_last_error(const kzg_ctx* ctx);
+
+/* ---- SRS: the G1 half of the reference's Vec<SetupArtifact> ------------------------------- */
+
+/* Ingests n blst_p1 values starting at first_g1 with a byte stride (= size_of::<SetupArtifact>(),
+ * reference src/trusted_setup.rs:31-35; the shim passes &srs[0].g1 so no field offset is
+ * assumed).  Points are Jacobian with arbitrary Z as blst_p1_mult leaves them
+ * (src/trusted_setup.rs:54-62); the library normalises them to affine on the device and builds
+ * its window tables.  `index_base` is the global index of first_g1 in the full SRS (0 for a
+ * single GPU; rank g of a sharded MSM passes its slice start and commits slice-relative). */
+int kzg_srs_load_g1(kzg_ctx* ctx, const void* first_g1, size_t stride_bytes, size_t n);
+
+/* Trusted setup on the device, G1 side only: SRS[i] = [s^i mod r]G1 for i in [first, first+n),
+ * s = secret read big-endian (reference src/trusted_setup.rs:20-28, 40-62).  Next-row component
+ * (SURVEY.md section 8f-2); it also makes the large bench configurations set up in seconds. */
+int kzg_srs_generate_g1(kzg_ctx* ctx, const uint8_t secret_be[32], uint64_t first, size_t n);
+
+/* Copies SRS entries [index, index+count) back as blst_p1 with Z = 1 (affine), e.g. to hand them
+ * to the reference's serde or to check them against blst. */
+int kzg_srs_read_g1(kzg_ctx* ctx, size_t index, size_t count, uint64_t* out_p1);
+size_t kzg_srs_len(const kzg_ctx* ctx);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+
+/* Polynomial::commit (reference src/polynomial.rs:200-215): out = sum_{i<n} coeffs[i] * SRS[i].
+ * coeffs = self.coefficients.as_ptr() (n x blst_fr, Montgomery).  n == 0 -> infinity.
+ * n > kzg_srs_len -> KZG_ERR_DEGREE_TOO_HIGH.  out_p1 is a blst_p1 with Z = 1 (Montgomery one) or
+ * all-zero for infinity, so G1Point::from(blst_p1) (src/curves.rs:13-17) wraps it directly. */
+int kzg_commit(kzg_ctx* ctx, const uint64_t* coeffs_fr_mont, size_t n, uint64_t out_p1[18]);
+
+/* Same with scalars as n x 32 canonical little-endian bytes (< r), i.e. what Scalar::to_le_bytes
+ * yields (reference src/scalar.rs:83-93) and what G1Point::mult feeds blst (src/curves.rs:93). */
+int kzg_commit_le_bytes(kzg_ctx* ctx, const uint8_t* scalars_le, size_t n, uint64_t out_p1[18]);
+
+/* Evaluation::generate_proof (reference src/polynomial.rs:260-269) fused on the device:
+ * (P - y) (:128-145) / (x - z) (:150-195) then commit.  z = evaluation.point, y = evaluation.result
+ * (4 x uint64 Montgomery each).  Error behaviour of the reference is reproduced:
+ *   n == 0 and y == 0 -> infinity;  constant polynomial: c0 == y -> infinity, else
+ *   KZG_ERR_CONSTANT_POLY;  P(z) != y -> KZG_ERR_REMAINDER;  quotient longer than the SRS ->
+ *   KZG_ERR_DEGREE_TOO_HIGH. */
+int kzg_open(kzg_ctx* ctx, const uint64_t* coeffs_fr_mont, size_t n, const uint64_t z[4],
+             const uint64_t y[4], uint64_t out_p1[18]);
+
+/* Polynomial::sub + divide_by_root alone (reference src/polynomial.rs:128-195): writes the
+ * quotient coefficients (Montgomery) to out_q (room for n-1 entries) and their count, after the
+ * reference's trailing-zero truncation, to *out_qn.  Same error codes as kzg_open. */
+int kzg_quotient(kzg_ctx* ctx, const uint64_t* coeffs_fr_mont, size_t n, const uint64_t z[4],
+                 const uint64_t y[4], uint64_t* out_q, size_t* out_qn);
+
+/* Polynomial::evaluate (reference src/polynomial.rs:112-123): y = P(z), the same device scan as the
+ * quotient (y is its remainder).  Next-row component. */
+int kzg_evaluate(kzg_ctx* ctx, const uint64_t* coeffs_fr_mont, size_t n, const uint64_t z[4],
+                 uint64_t out_y[4]);
+
+/* ---- device-resident / pipelined variants -------------------------------------------------
+ * d_coeffs is a DEVICE pointer (n x blst_fr, Montgomery) on the context's GPU, e.g. a tensor
+ * produced upstream.  submit enqueues on one of kzg_num_slots() internal HIP streams and returns
+ * at once; wait blocks on that slot, finishes the tail on the host and writes the result.  Several
+ * slots in flight keep the GPU busy across the latency-bound end of each MSM. */
+int kzg_num_slots(const kzg_ctx* ctx);
+int kzg_commit_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n);
+int kzg_open_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, const uint64_t z[4],
+                    const uint64_t y[4]);
+int kzg_wait(kzg_ctx* ctx, int slot, uint64_t out_p1[18]);
+
+/* raw device memory helpers so a non-HIP host (Rust, Python) can stage device-resident inputs */
+int kzg_dev_alloc(kzg_ctx* ctx, size_t bytes, void** out_dptr);
+int kzg_dev_free(kzg_ctx* ctx, void* dptr);
+int kzg_dev_upload(kzg_ctx* ctx, void* dst_dptr, const void* src_host, size_t bytes);
+int kzg_dev_download(kzg_ctx* ctx, void* dst_host, const void* src_dptr, size_t bytes);
+
+/* ---- G1 helpers on the host side of the boundary ------------------------------------------ */
+
+/* Sum of k blst_p1 values, normalised like kzg_commit's output.  This is the "reduce" of the
+ * multi-GPU MSM: each rank commits its SRS slice, the partial sums are all-gathered over RCCL and
+ * every rank (or rank 0) calls this (blst_p1_add_or_double semantics, reference src/curves.rs:79-85). */
+int kzg_g1_sum(const uint64_t* p1s, size_t k, uint64_t out_p1[18]);
+
+/* ZCash 48-byte compression = what the reference's `Serialize for G1Point` emits
+ * (reference src/curves.rs:99-110 -> blst_p1_compress).  The parity comparator. */
+int kzg_g1_compress(const uint64_t p1[18], uint8_t out[48]);
+
+/* ---- measurement -------------------------------------------------------------------------- */
+
+typedef struct kzg_kernel_times {
+    /* per-kernel HIP-event times of the most recent kzg_wait on the slot, milliseconds, measured on
+     * the stream the kernels ran on (only filled while timing is enabled) */
+    float digits_ms;      /* scalar recoding + bucket histogram */
+    float scan_ms;        /* bucket offsets (+ bucket ordering) */
+    float scatter_ms;     /* counting-sort scatter of (point, sign) references */
+    float accumulate_ms;  /* bucket accumulation: the dominant kernel */
+    float reduce_ms;      /* bucket running-sum reduction levels */
+    float quotient_ms;    /* open only: scalar-field synthetic division */
+    float total_ms;       /* first kernel start -> last kernel end */
+} kzg_kernel_times;
+
+int kzg_set_timing(kzg_ctx* ctx, int enabled);
+int kzg_get_times(kzg_ctx* ctx, int slot, kzg_kernel_times* out);
+/* window bits / number of windows / number of buckets chosen for the loaded SRS */
+int kzg_msm_config(const kzg_ctx* ctx, int* window_bits, int* num_windows, size_t* num_buckets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KZG_MI355X_H */

@@ -1,0 +1,450 @@
+"""kzg_poly_commit_exploration_amd -- host-side mirror of the reference's commit / open API over
+the MI355X engine (libkzg_mi355x.so, C-ABI in include/kzg_mi355x.h).
+
+The names follow the reference crate (VGLoic/kzg-poly-commit-exploration): Scalar
+(src/scalar.rs), G1Point (src/curves.rs), SetupArtifactsGenerator (src/trusted_setup.rs),
+Polynomial / Evaluation (src/polynomial.rs) -- same argument meaning, same error messages -- so
+the parity tests read like the reference's own tests (src/lib.rs:16-33).  Everything that is
+arithmetic on the hot path goes through the C-ABI into HIP kernels; this module only converts
+representations (Python ints <-> blst limb layouts), which is what the reference's Rust host code
+does around its blst calls.  There is no CPU fallback: importing works without a GPU, creating an
+Engine does not.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+__all__ = [
+    "Engine", "Scalar", "G1Point", "Polynomial", "Evaluation", "SetupArtifactsGenerator", "KzgError",
+    "R_MODULUS", "lib_path", "load_library", "ABI_SYMBOLS",
+]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+R_MODULUS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001  # src/scalar.rs:10
+_FR_R = 1 << 256
+_FR_RINV = pow(_FR_R, -1, R_MODULUS)
+
+KZG_OK = 0
+KZG_ERR_DEGREE_TOO_HIGH = -1
+KZG_ERR_CONSTANT_POLY = -2
+KZG_ERR_REMAINDER = -3
+KZG_ERR_INVALID_ARG = -4
+KZG_ERR_NO_DEVICE = -5
+KZG_ERR_HIP = -6
+KZG_ERR_NO_SRS = -7
+KZG_ERR_BUSY = -8
+
+# every symbol include/kzg_mi355x.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "kzg_ctx_create", "kzg_ctx_destroy", "kzg_strerror", "kzg_last_error",
+    "kzg_srs_load_g1", "kzg_srs_generate_g1", "kzg_srs_read_g1", "kzg_srs_len",
+    "kzg_commit", "kzg_commit_le_bytes", "kzg_open", "kzg_quotient", "kzg_evaluate",
+    "kzg_num_slots", "kzg_commit_submit", "kzg_open_submit", "kzg_wait",
+    "kzg_dev_alloc", "kzg_dev_free", "kzg_dev_upload", "kzg_dev_download",
+    "kzg_g1_sum", "kzg_g1_compress", "kzg_set_timing", "kzg_get_times", "kzg_msm_config",
+]
+
+
+class KzgError(Exception):
+    """Carries the reference's anyhow message for the three errors of the path."""
+
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+class KernelTimes(C.Structure):
+    _fields_ = [(n, C.c_float) for n in
+                ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "quotient_ms", "total_ms")]
+
+
+def lib_path():
+    return os.path.join(_HERE, "libkzg_mi355x.so")
+
+
+_LIB = None
+
+
+def load_library():
+    """Loads the C-ABI library.  Fails loudly if it has not been built (no fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            "libkzg_mi355x.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The product has no CPU path.")
+    lib = C.CDLL(path)
+    vp, sz, u8p, i = C.c_void_p, C.c_size_t, C.c_char_p, C.c_int
+    sig = {
+        "kzg_ctx_create": (i, [i, C.POINTER(vp)]),
+        "kzg_ctx_destroy": (None, [vp]),
+        "kzg_strerror": (C.c_char_p, [i]),
+        "kzg_last_error": (C.c_char_p, [vp]),
+        "kzg_srs_load_g1": (i, [vp, vp, sz, sz]),
+        "kzg_srs_generate_g1": (i, [vp, u8p, C.c_uint64, sz]),
+        "kzg_srs_read_g1": (i, [vp, sz, sz, vp]),
+        "kzg_srs_len": (sz, [vp]),
+        "kzg_commit": (i, [vp, vp, sz, vp]),
+        "kzg_commit_le_bytes": (i, [vp, vp, sz, vp]),
+        "kzg_open": (i, [vp, vp, sz, vp, vp, vp]),
+        "kzg_quotient": (i, [vp, vp, sz, vp, vp, vp, C.POINTER(sz)]),
+        "kzg_evaluate": (i, [vp, vp, sz, vp, vp]),
+        "kzg_num_slots": (i, [vp]),
+        "kzg_commit_submit": (i, [vp, i, vp, sz]),
+        "kzg_open_submit": (i, [vp, i, vp, sz, vp, vp]),
+        "kzg_wait": (i, [vp, i, vp]),
+        "kzg_dev_alloc": (i, [vp, sz, C.POINTER(vp)]),
+        "kzg_dev_free": (i, [vp, vp]),
+        "kzg_dev_upload": (i, [vp, vp, vp, sz]),
+        "kzg_dev_download": (i, [vp, vp, vp, sz]),
+        "kzg_g1_sum": (i, [vp, sz, vp]),
+        "kzg_g1_compress": (i, [vp, vp]),
+        "kzg_set_timing": (i, [vp, i]),
+        "kzg_get_times": (i, [vp, i, C.POINTER(KernelTimes)]),
+        "kzg_msm_config": (i, [vp, C.POINTER(i), C.POINTER(i), C.POINTER(sz)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    _LIB = lib
+    return lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# ---------------------------------------------------------------------------------------------
+# Scalar: reference src/scalar.rs.  Value semantics on a canonical integer; `limbs()` is the
+# blst_fr memory image (4 x u64, Montgomery) that crosses the C-ABI.
+# ---------------------------------------------------------------------------------------------
+class Scalar:
+    __slots__ = ("v",)
+
+    def __init__(self, v=0):
+        self.v = int(v) % R_MODULUS
+
+    @staticmethod
+    def from_i128(a):  # src/scalar.rs:27-48: a > 0 -> a ; a <= 0 -> r - |a|
+        a = int(a)
+        if not -(1 << 127) <= a < (1 << 127):
+            raise OverflowError("not an i128")
+        return Scalar(a if a > 0 else R_MODULUS - (-a))
+
+    @staticmethod
+    def from_le_bytes(b):  # src/scalar.rs:54-61
+        assert len(b) == 32
+        return Scalar(int.from_bytes(bytes(b), "little"))
+
+    @staticmethod
+    def from_be_bytes(b):  # src/scalar.rs:66-73
+        assert len(b) == 32
+        return Scalar(int.from_bytes(bytes(b), "big"))
+
+    @staticmethod
+    def from_limbs(l):
+        raw = sum(int(x) << (64 * i) for i, x in enumerate(l))
+        return Scalar(raw * _FR_RINV)
+
+    def to_le_bytes(self):  # src/scalar.rs:83-93
+        return self.v.to_bytes(32, "little")
+
+    def to_be_bytes(self):  # src/scalar.rs:96-106
+        return self.v.to_bytes(32, "big")
+
+    def limbs(self):
+        m = self.v * _FR_R % R_MODULUS
+        return np.array([(m >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)], dtype=np.uint64)
+
+    def mul(self, o):
+        return Scalar(self.v * o.v)
+
+    def add(self, o):
+        return Scalar(self.v + o.v)
+
+    def sub(self, o):
+        return Scalar(self.v - o.v)
+
+    def neg(self):
+        return Scalar(-self.v)
+
+    def pow(self, n):  # src/scalar.rs:122-187 (same value)
+        return Scalar(pow(self.v, int(n), R_MODULUS))
+
+    def is_zero(self):
+        return self.v == 0
+
+    def __eq__(self, o):
+        return isinstance(o, Scalar) and self.v == o.v
+
+    def __hash__(self):
+        return hash(self.v)
+
+    def __repr__(self):
+        return "Scalar(%d)" % self.v
+
+    def __str__(self):  # base-10 Display, src/scalar.rs:277-341
+        return str(self.v)
+
+
+def scalars_to_limbs(values):
+    """ints (canonical, any sign) -> (n, 4) uint64 Montgomery blst_fr array."""
+    out = np.empty((len(values), 4), dtype=np.uint64)
+    mask = 0xFFFFFFFFFFFFFFFF
+    for i, v in enumerate(values):
+        m = (int(v) % R_MODULUS) * _FR_R % R_MODULUS
+        out[i, 0] = m & mask
+        out[i, 1] = (m >> 64) & mask
+        out[i, 2] = (m >> 128) & mask
+        out[i, 3] = m >> 192
+    return out
+
+
+def limbs_to_scalars(arr):
+    arr = np.asarray(arr, dtype=np.uint64).reshape(-1, 4)
+    out = []
+    for row in arr:
+        raw = int(row[0]) | (int(row[1]) << 64) | (int(row[2]) << 128) | (int(row[3]) << 192)
+        out.append(raw * _FR_RINV % R_MODULUS)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# G1Point: reference src/curves.rs:10-17 (a wrapped blst_p1).  Serialisation = 48 compressed bytes
+# (src/curves.rs:99-110), which is also how two points are compared for parity.
+# ---------------------------------------------------------------------------------------------
+class G1Point:
+    __slots__ = ("p1",)
+
+    def __init__(self, p1):
+        self.p1 = np.ascontiguousarray(p1, dtype=np.uint64).reshape(18)
+
+    def compress(self):
+        out = (C.c_ubyte * 48)()
+        rc = load_library().kzg_g1_compress(_ptr(self.p1), C.cast(out, C.c_void_p))
+        _check(rc)
+        return bytes(out)
+
+    def is_infinity(self):
+        return not self.p1[12:18].any()
+
+    def add(self, other):  # src/curves.rs:79-85
+        return G1Point.sum([self, other])
+
+    @staticmethod
+    def sum(points):
+        arr = np.ascontiguousarray(np.stack([p.p1 for p in points]), dtype=np.uint64)
+        out = np.zeros(18, dtype=np.uint64)
+        _check(load_library().kzg_g1_sum(_ptr(arr), len(points), _ptr(out)))
+        return G1Point(out)
+
+    def __eq__(self, o):
+        return isinstance(o, G1Point) and self.compress() == o.compress()
+
+    def __repr__(self):
+        return "G1Point(%s)" % self.compress().hex()
+
+
+def _check(rc, ctx=None):
+    if rc == KZG_OK:
+        return
+    lib = load_library()
+    msg = lib.kzg_strerror(rc).decode()
+    if rc == KZG_ERR_HIP and ctx is not None:
+        msg += ": " + lib.kzg_last_error(ctx).decode()
+    raise KzgError(rc, msg)
+
+
+# ---------------------------------------------------------------------------------------------
+# Engine: one context = one GPU with a resident SRS (no reference analogue; see kzg_mi355x.h).
+# ---------------------------------------------------------------------------------------------
+class Engine:
+    def __init__(self, device=0):
+        self._lib = load_library()
+        h = C.c_void_p()
+        _check(self._lib.kzg_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.kzg_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- SRS --
+    def srs_load(self, p1_array, stride=None):
+        """p1_array: (n, k>=18) uint64 rows starting with a blst_p1 (the g1 of a SetupArtifact)."""
+        a = np.ascontiguousarray(p1_array, dtype=np.uint64)
+        n = a.shape[0]
+        stride = a.strides[0] if stride is None else stride
+        _check(self._lib.kzg_srs_load_g1(self._h, _ptr(a), stride, n), self._h)
+
+    def srs_generate(self, secret_be, n, first=0):
+        _check(self._lib.kzg_srs_generate_g1(self._h, bytes(secret_be), first, n), self._h)
+
+    def srs_read(self, index, count):
+        out = np.zeros((count, 18), dtype=np.uint64)
+        _check(self._lib.kzg_srs_read_g1(self._h, index, count, _ptr(out)), self._h)
+        return out
+
+    def srs_len(self):
+        return int(self._lib.kzg_srs_len(self._h))
+
+    def msm_config(self):
+        c, w, nb = C.c_int(), C.c_int(), C.c_size_t()
+        _check(self._lib.kzg_msm_config(self._h, C.byref(c), C.byref(w), C.byref(nb)))
+        return {"window_bits": c.value, "windows": w.value, "buckets": nb.value}
+
+    # -- hot path, host buffers --
+    def commit_limbs(self, coeffs):
+        a = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        out = np.zeros(18, dtype=np.uint64)
+        _check(self._lib.kzg_commit(self._h, _ptr(a), a.shape[0], _ptr(out)), self._h)
+        return G1Point(out)
+
+    def commit_le_bytes(self, scalars_le):
+        a = np.ascontiguousarray(np.frombuffer(bytes(scalars_le), dtype=np.uint8))
+        out = np.zeros(18, dtype=np.uint64)
+        _check(self._lib.kzg_commit_le_bytes(self._h, _ptr(a), a.size // 32, _ptr(out)), self._h)
+        return G1Point(out)
+
+    def open_limbs(self, coeffs, z, y):
+        a = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        zl, yl = z.limbs(), y.limbs()
+        out = np.zeros(18, dtype=np.uint64)
+        _check(self._lib.kzg_open(self._h, _ptr(a), a.shape[0], _ptr(zl), _ptr(yl), _ptr(out)), self._h)
+        return G1Point(out)
+
+    def quotient_limbs(self, coeffs, z, y):
+        a = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        zl, yl = z.limbs(), y.limbs()
+        q = np.zeros((max(a.shape[0], 1), 4), dtype=np.uint64)
+        qn = C.c_size_t(0)
+        _check(self._lib.kzg_quotient(self._h, _ptr(a), a.shape[0], _ptr(zl), _ptr(yl), _ptr(q), C.byref(qn)), self._h)
+        return q[: qn.value].copy()
+
+    def evaluate_limbs(self, coeffs, z):
+        a = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+        zl = z.limbs()
+        out = np.zeros(4, dtype=np.uint64)
+        _check(self._lib.kzg_evaluate(self._h, _ptr(a), a.shape[0], _ptr(zl), _ptr(out)), self._h)
+        return Scalar.from_limbs(out)
+
+    # -- device-resident, pipelined --
+    def num_slots(self):
+        return int(self._lib.kzg_num_slots(self._h))
+
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        _check(self._lib.kzg_dev_alloc(self._h, nbytes, C.byref(p)), self._h)
+        return p.value
+
+    def dev_free(self, dptr):
+        _check(self._lib.kzg_dev_free(self._h, C.c_void_p(dptr)), self._h)
+
+    def dev_upload(self, dptr, array):
+        a = np.ascontiguousarray(array)
+        _check(self._lib.kzg_dev_upload(self._h, C.c_void_p(dptr), _ptr(a), a.nbytes), self._h)
+
+    def commit_submit(self, slot, dptr, n):
+        _check(self._lib.kzg_commit_submit(self._h, slot, C.c_void_p(dptr), n), self._h)
+
+    def open_submit(self, slot, dptr, n, z, y):
+        zl, yl = z.limbs(), y.limbs()
+        _check(self._lib.kzg_open_submit(self._h, slot, C.c_void_p(dptr), n, _ptr(zl), _ptr(yl)), self._h)
+
+    def wait(self, slot):
+        out = np.zeros(18, dtype=np.uint64)
+        _check(self._lib.kzg_wait(self._h, slot, _ptr(out)), self._h)
+        return G1Point(out)
+
+    # -- measurement --
+    def set_timing(self, enabled):
+        _check(self._lib.kzg_set_timing(self._h, 1 if enabled else 0))
+
+    def times(self, slot):
+        t = KernelTimes()
+        _check(self._lib.kzg_get_times(self._h, slot, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in KernelTimes._fields_}
+
+
+# ---------------------------------------------------------------------------------------------
+# SetupArtifactsGenerator: reference src/trusted_setup.rs:9-29 / 37-78.  `take(n)` materialises the
+# first n artifacts -- on the device, G1 side -- and returns the engine that now holds them; the
+# reference's `Vec<SetupArtifact>` argument of commit / generate_proof becomes that engine.
+# ---------------------------------------------------------------------------------------------
+class SetupArtifactsGenerator:
+    def __init__(self, secret_be, device=0):
+        assert len(secret_be) == 32
+        self.secret = bytes(secret_be)
+        self.device = device
+
+    def take(self, n, engine=None):
+        eng = engine or Engine(self.device)
+        eng.srs_generate(self.secret, n)
+        return eng
+
+
+# ---------------------------------------------------------------------------------------------
+# Polynomial / Evaluation: reference src/polynomial.rs
+# ---------------------------------------------------------------------------------------------
+class Polynomial:
+    def __init__(self, limbs):
+        self.limbs = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, 4)
+
+    @staticmethod
+    def try_from(values):
+        """TryFrom<Vec<i128>> / TryFrom<Vec<Scalar>> (src/polynomial.rs:14-76): trailing zeros are
+        dropped, index 0 is kept."""
+        if len(values) > 0xFFFFFFFF:
+            raise KzgError(KZG_ERR_INVALID_ARG,
+                           "Too many coefficients for polynomial, only 2**32 - 1 coefficients is supported. Got %d"
+                           % len(values))
+        ints = [v.v if isinstance(v, Scalar) else Scalar.from_i128(v).v for v in values]
+        last = 0
+        for i, v in enumerate(ints):
+            if v != 0:
+                last = i
+        ints = ints[: last + 1] if ints else []
+        return Polynomial(scalars_to_limbs(ints))
+
+    @staticmethod
+    def from_limbs(limbs):
+        """Takes blst_fr rows as they are (applies the same truncation)."""
+        a = np.ascontiguousarray(limbs, dtype=np.uint64).reshape(-1, 4)
+        nz = np.flatnonzero(a.any(axis=1))
+        last = int(nz[-1]) if nz.size else 0
+        return Polynomial(a[: last + 1] if a.shape[0] else a)
+
+    def degree(self):  # src/polynomial.rs:93-98
+        return 0 if self.limbs.shape[0] == 0 else self.limbs.shape[0] - 1
+
+    def coefficients(self):
+        return [Scalar(v) for v in limbs_to_scalars(self.limbs)]
+
+    def commit(self, setup):  # src/polynomial.rs:200-215
+        return setup.commit_limbs(self.limbs)
+
+    def evaluate(self, x, setup):  # src/polynomial.rs:112-123
+        return Evaluation(x, setup.evaluate_limbs(self.limbs, x))
+
+    def divide_by_root_minus(self, root, y, setup):
+        """(self - y).divide_by_root(root): src/polynomial.rs:128-195."""
+        return Polynomial(setup.quotient_limbs(self.limbs, root, y))
+
+
+class Evaluation:
+    def __init__(self, point, result):
+        self.point, self.result = point, result
+
+    def generate_proof(self, polynomial, setup):  # src/polynomial.rs:260-269
+        return setup.open_limbs(polynomial.limbs, self.point, self.result)

@@ -1,0 +1,790 @@
+// api.hip -- the C-ABI of libkzg_mi355x.so (declared in include/kzg_mi355x.h): context, SRS
+// residency, stream slots, the host-side orchestration of one commitment / opening, and the serial
+// tail (a few dozen point additions + one inversion) that finishes each MSM on the host.
+//
+// One commitment on a slot's stream:
+//   memset(hist) -> digits+histogram -> scan -> scatter -> bucket accumulation
+//   -> weighted running-sum levels (+ plain chunk sums of each level's acc[]) -> D2H of <= a few
+//   hundred XYZZ partials -> host: Horner over the levels, normalise, blst_p1 out.
+// Nothing here falls back to the CPU for the MSM or the division: without a device the context
+// cannot be created.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kzg_mi355x.h"
+#include "engine.h"
+#include "host_field.hpp"
+
+using namespace kzg;
+namespace hf = kzg_host;
+
+namespace {
+
+constexpr int kNumSlots = 3;
+constexpr uint32_t kWsumM = 4;      // chunk of the weighted running-sum levels
+constexpr uint32_t kSumM = 8;       // fan-in of the plain chunk sums
+constexpr uint32_t kFinalMax = 32;  // partials per level handed to the host
+
+struct Level {
+    uint32_t n_items;   // items entering the level
+    uint32_t chunks;    // = ceil(n_items / kWsumM): size of acc[] and run[]
+    size_t acc_off;     // XYZZ record offsets into the reduce arena
+    size_t run_off;
+    uint32_t n_final;   // partials of this level copied to the host
+    size_t final_off;   // record offset in the final buffer
+};
+
+enum SlotKind { SLOT_IDLE = 0, SLOT_COMMIT = 1, SLOT_OPEN = 2, SLOT_TRIVIAL = 3 };
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    hipEvent_t done = nullptr;
+    // MSM workspace (sized at SRS load)
+    uint32_t *d_hist = nullptr, *d_offs = nullptr, *d_block_sums = nullptr;
+    uint32_t *d_rank = nullptr, *d_sorted = nullptr;
+    void* d_buckets = nullptr;
+    void* d_arena = nullptr;     // acc[] / run[] of every level
+    void* d_sumtmp[2] = {nullptr, nullptr};
+    void* d_final = nullptr;
+    uint64_t* h_final = nullptr;  // pinned
+    // polynomial workspace (grown on demand)
+    size_t poly_cap = 0;
+    uint32_t* d_stage = nullptr;  // coefficients copied from the host
+    uint32_t* d_q = nullptr;      // quotient
+    uint32_t* d_chunk = nullptr;
+    uint32_t* d_block = nullptr;
+    uint32_t* d_small = nullptr;  // [0..1] flags, [8..15] P(z), [16..23] c0, [24] tail flag
+    uint32_t* h_small = nullptr;  // pinned mirror
+    // state of the job in flight
+    SlotKind kind = SLOT_IDLE;
+    size_t job_n = 0;
+    uint32_t open_y[8] = {};
+    bool timing = false;
+    bool has_quotient = false;
+    bool tail_checked = false;
+    kzg_kernel_times times = {};
+};
+
+}  // namespace
+
+struct kzg_ctx {
+    int device = 0;
+    std::mutex mu;
+    std::string last_error;
+    // SRS
+    size_t n = 0;  // points
+    MsmConfig cfg = {};
+    void* d_table = nullptr;  // W * n affine points
+    std::vector<Level> levels;
+    size_t arena_records = 0, final_records = 0, sumtmp_records = 0;
+    Slot slots[kNumSlots];
+    bool slots_ready = false;
+    bool timing = false;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);                  \
+            return KZG_ERR_HIP;                                                                     \
+        }                                                                                           \
+    } while (0)
+
+void free_slot_msm(Slot& s) {
+    hipFree(s.d_hist); hipFree(s.d_offs); hipFree(s.d_block_sums); hipFree(s.d_rank); hipFree(s.d_sorted);
+    hipFree(s.d_buckets); hipFree(s.d_arena); hipFree(s.d_sumtmp[0]); hipFree(s.d_sumtmp[1]); hipFree(s.d_final);
+    if (s.h_final) hipHostFree(s.h_final);
+    s.d_hist = s.d_offs = s.d_block_sums = s.d_rank = s.d_sorted = nullptr;
+    s.d_buckets = s.d_arena = s.d_sumtmp[0] = s.d_sumtmp[1] = s.d_final = nullptr;
+    s.h_final = nullptr;
+}
+void free_slot_poly(Slot& s) {
+    hipFree(s.d_stage); hipFree(s.d_q); hipFree(s.d_chunk); hipFree(s.d_block);
+    s.d_stage = s.d_q = s.d_chunk = s.d_block = nullptr;
+    s.poly_cap = 0;
+}
+
+int ensure_poly(kzg_ctx* ctx, Slot& s, size_t n) {
+    if (n <= s.poly_cap && s.d_stage) return KZG_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    free_slot_poly(s);
+    size_t cap = n < 1024 ? 1024 : n;
+    HIP_TRY(ctx, hipMalloc(&s.d_stage, cap * 32));
+    HIP_TRY(ctx, hipMalloc(&s.d_q, cap * 32));
+    HIP_TRY(ctx, hipMalloc(&s.d_chunk, poly_chunk_words((uint32_t)cap) * 4));
+    HIP_TRY(ctx, hipMalloc(&s.d_block, poly_block_words((uint32_t)cap) * 4));
+    s.poly_cap = cap;
+    return KZG_OK;
+}
+
+// reduction plan: depends only on the bucket count
+void plan_levels(kzg_ctx* ctx) {
+    ctx->levels.clear();
+    size_t arena = 0, fin = 0;
+    uint32_t n_items = ctx->cfg.nb;
+    size_t sumtmp = 0;
+    while (true) {
+        Level L;
+        L.n_items = n_items;
+        L.chunks = (n_items + kWsumM - 1) / kWsumM;
+        L.acc_off = arena;
+        arena += L.chunks;
+        L.run_off = arena;
+        arena += L.chunks;
+        uint32_t cnt = L.chunks;
+        bool first = true;
+        while (cnt > kFinalMax) {
+            cnt = (cnt + kSumM - 1) / kSumM;
+            if (first && cnt > sumtmp) sumtmp = cnt;
+            first = false;
+        }
+        L.n_final = cnt;
+        L.final_off = fin;
+        fin += cnt;
+        ctx->levels.push_back(L);
+        if (L.chunks <= 1) break;
+        n_items = L.chunks - 1;  // run[1..] carry weights 1..
+    }
+    ctx->arena_records = arena;
+    ctx->final_records = fin;
+    ctx->sumtmp_records = sumtmp ? sumtmp : 1;
+}
+
+int setup_slots(kzg_ctx* ctx) {
+    plan_levels(ctx);
+    const MsmConfig cfg = ctx->cfg;
+    const size_t pairs = (size_t)cfg.W * ctx->n;
+    for (int i = 0; i < kNumSlots; i++) {
+        Slot& s = ctx->slots[i];
+        if (!s.stream) {
+            HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+            for (auto& e : s.ev) HIP_TRY(ctx, hipEventCreate(&e));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+            HIP_TRY(ctx, hipMalloc(&s.d_small, 64 * 4));
+            HIP_TRY(ctx, hipHostMalloc(&s.h_small, 64 * 4));
+        }
+        free_slot_msm(s);
+        HIP_TRY(ctx, hipMalloc(&s.d_hist, (size_t)cfg.nb * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_offs, ((size_t)cfg.nb + 1) * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_block_sums, 1024 * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_rank, (pairs ? pairs : 1) * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_sorted, (pairs ? pairs : 1) * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_buckets, (size_t)cfg.nb * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_arena, ctx->arena_records * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_sumtmp[0], ctx->sumtmp_records * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_sumtmp[1], ctx->sumtmp_records * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_final, ctx->final_records * kXyzzBytes));
+        HIP_TRY(ctx, hipHostMalloc(&s.h_final, ctx->final_records * kXyzzBytes));
+        s.kind = SLOT_IDLE;
+    }
+    ctx->slots_ready = true;
+    return KZG_OK;
+}
+
+// builds windows 1..W-1 of the table from window 0 (already in d_table[0..n))
+int build_tables(kzg_ctx* ctx, hipStream_t st, void* d_xyzz_tmp, void* d_prefix) {
+    const size_t n = ctx->n;
+    for (uint32_t j = 1; j < ctx->cfg.W; j++) {
+        char* prev = (char*)ctx->d_table + (size_t)(j - 1) * n * kAffineBytes;
+        char* next = (char*)ctx->d_table + (size_t)j * n * kAffineBytes;
+        launch_table_window(st, prev, (uint32_t)n, ctx->cfg.c, d_xyzz_tmp, d_prefix, next);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    return KZG_OK;
+}
+
+int drain_all(kzg_ctx* ctx) {
+    for (auto& s : ctx->slots)
+        if (s.stream) HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    return KZG_OK;
+}
+
+int srs_prepare(kzg_ctx* ctx, size_t n) {
+    if (n == 0 || n > 0x7fffffffu / 32) return KZG_ERR_INVALID_ARG;
+    int rc = drain_all(ctx);
+    if (rc) return rc;
+    for (auto& s : ctx->slots) s.kind = SLOT_IDLE;
+    if (ctx->d_table) {
+        hipFree(ctx->d_table);
+        ctx->d_table = nullptr;
+    }
+    ctx->n = 0;
+    MsmConfig cfg = choose_msm_config(n);
+    if ((size_t)cfg.W * n >= 0x80000000ull) return KZG_ERR_INVALID_ARG;  // table index must fit 31 bits
+    ctx->cfg = cfg;
+    HIP_TRY(ctx, hipMalloc(&ctx->d_table, (size_t)cfg.W * n * kAffineBytes));
+    return KZG_OK;
+}
+
+// enqueue the MSM over n scalars at d_scalars on slot s
+int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, size_t n, int ev_base) {
+    const MsmConfig cfg = ctx->cfg;
+    hipStream_t st = s.stream;
+    HIP_TRY(ctx, hipMemsetAsync(s.d_hist, 0, (size_t)cfg.nb * 4, st));
+    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base], st));
+    launch_digits_hist(st, d_scalars, is_mont, (uint32_t)n, cfg, s.d_hist, s.d_rank);
+    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 1], st));
+    launch_bucket_scan(st, s.d_hist, cfg.nb, s.d_offs, s.d_block_sums);
+    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 2], st));
+    launch_scatter(st, d_scalars, is_mont, (uint32_t)n, (uint32_t)ctx->n, cfg, s.d_offs, s.d_rank, s.d_sorted);
+    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 3], st));
+    launch_bucket_accumulate(st, ctx->d_table, s.d_sorted, s.d_offs, nullptr, cfg.nb, s.d_buckets);
+    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], st));
+    // reduction levels
+    const char* items = (const char*)s.d_buckets;
+    for (size_t li = 0; li < ctx->levels.size(); li++) {
+        const Level& L = ctx->levels[li];
+        char* acc = (char*)s.d_arena + L.acc_off * kXyzzBytes;
+        char* run = (char*)s.d_arena + L.run_off * kXyzzBytes;
+        launch_wsum_level(st, items, L.n_items, kWsumM, acc, run);
+        const char* cur = acc;
+        uint32_t cnt = L.chunks;
+        int pp = 0;
+        while (cnt > kFinalMax) {
+            launch_sum_level(st, cur, cnt, kSumM, s.d_sumtmp[pp]);
+            cur = (const char*)s.d_sumtmp[pp];
+            cnt = (cnt + kSumM - 1) / kSumM;
+            pp ^= 1;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync((char*)s.d_final + L.final_off * kXyzzBytes, cur, (size_t)cnt * kXyzzBytes,
+                                    hipMemcpyDeviceToDevice, st));
+        items = run + kXyzzBytes;  // run[1..]
+    }
+    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 5], st));
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_final, s.d_final, ctx->final_records * kXyzzBytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipGetLastError());
+    return KZG_OK;
+}
+
+// host tail: total = A_0 + m (A_1 + m (A_2 + ...)),  A_l = sum of level l's partials
+hf::P1 finish_msm(const kzg_ctx* ctx, const Slot& s) {
+    hf::P1 acc = hf::p1_inf();
+    uint32_t log_m = 0;
+    while ((1u << log_m) < kWsumM) log_m++;
+    for (size_t li = ctx->levels.size(); li-- > 0;) {
+        const Level& L = ctx->levels[li];
+        for (uint32_t k = 0; k < log_m; k++) acc = hf::p1_double(acc);
+        for (uint32_t k = 0; k < L.n_final; k++)
+            acc = hf::p1_add(acc, hf::p1_from_xyzz(s.h_final + (L.final_off + k) * kXyzzWords64));
+    }
+    return hf::p1_normalize(acc);
+}
+
+void write_p1(uint64_t out[18], const hf::P1& p) { std::memcpy(out, &p, sizeof p); }
+
+bool host_tail_nonzero(const uint64_t* coeffs, size_t from, size_t n) {
+    for (size_t i = from; i < n; i++)
+        if (coeffs[4 * i] | coeffs[4 * i + 1] | coeffs[4 * i + 2] | coeffs[4 * i + 3]) return true;
+    return false;
+}
+
+}  // namespace
+
+// a tiny kernel for the device-pointer entry points: any non-zero Fr in [from, n)?
+__global__ void k_tail_nonzero(const uint32_t* __restrict__ c, uint64_t from, uint64_t n, uint32_t* __restrict__ flag) {
+    uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint4* p = reinterpret_cast<const uint4*>(c) + 2 * i;
+    uint4 a = p[0], b = p[1];
+    if (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) atomicOr(flag, 1u);
+}
+
+extern "C" {
+
+const char* kzg_strerror(int status) {
+    switch (status) {
+        case KZG_OK: return "ok";
+        case KZG_ERR_DEGREE_TOO_HIGH:
+            return "Setup does not allow for commitment generation of the polynomial. The polynomial degree is too high.";
+        case KZG_ERR_CONSTANT_POLY: return "Unable to divide a constant polynomial";
+        case KZG_ERR_REMAINDER:
+            return "[divide_by_root] Fail to divide the polynomial by a root, constant terms do not add up";
+        case KZG_ERR_INVALID_ARG: return "invalid argument";
+        case KZG_ERR_NO_DEVICE: return "no HIP device available (this library has no CPU path)";
+        case KZG_ERR_HIP: return "HIP runtime error";
+        case KZG_ERR_NO_SRS: return "no SRS loaded";
+        case KZG_ERR_BUSY: return "slot busy";
+        default: return "unknown status";
+    }
+}
+
+const char* kzg_last_error(const kzg_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int kzg_ctx_create(int device, kzg_ctx** out) {
+    if (!out) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return KZG_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return KZG_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return KZG_ERR_NO_DEVICE;
+    kzg_ctx* ctx = new kzg_ctx();
+    ctx->device = device;
+    *out = ctx;
+    return KZG_OK;
+}
+
+void kzg_ctx_destroy(kzg_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    for (auto& s : ctx->slots) {
+        if (s.stream) hipStreamSynchronize(s.stream);
+        free_slot_msm(s);
+        free_slot_poly(s);
+        if (s.d_small) hipFree(s.d_small);
+        if (s.h_small) hipHostFree(s.h_small);
+        for (auto& e : s.ev)
+            if (e) hipEventDestroy(e);
+        if (s.done) hipEventDestroy(s.done);
+        if (s.stream) hipStreamDestroy(s.stream);
+    }
+    if (ctx->d_table) hipFree(ctx->d_table);
+    delete ctx;
+}
+
+size_t kzg_srs_len(const kzg_ctx* ctx) { return ctx ? ctx->n : 0; }
+int kzg_num_slots(const kzg_ctx*) { return kNumSlots; }
+
+int kzg_msm_config(const kzg_ctx* ctx, int* window_bits, int* num_windows, size_t* num_buckets) {
+    if (!ctx || !ctx->n) return KZG_ERR_NO_SRS;
+    if (window_bits) *window_bits = (int)ctx->cfg.c;
+    if (num_windows) *num_windows = (int)ctx->cfg.W;
+    if (num_buckets) *num_buckets = ctx->cfg.nb;
+    return KZG_OK;
+}
+
+int kzg_srs_load_g1(kzg_ctx* ctx, const void* first_g1, size_t stride, size_t n) {
+    if (!ctx || !first_g1 || stride < 144) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = srs_prepare(ctx, n);
+    if (rc) return rc;
+    // gather the strided blst_p1 values, upload, normalise to affine = window 0
+    std::vector<uint64_t> packed(n * 18);
+    for (size_t i = 0; i < n; i++) std::memcpy(&packed[i * 18], (const char*)first_g1 + i * stride, 144);
+    void *d_jac = nullptr, *d_prefix = nullptr, *d_xyzz = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_jac, n * 144));
+    HIP_TRY(ctx, hipMalloc(&d_prefix, n * 48));
+    HIP_TRY(ctx, hipMalloc(&d_xyzz, n * kXyzzBytes));
+    hipStream_t st = nullptr;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipMemcpyAsync(d_jac, packed.data(), n * 144, hipMemcpyHostToDevice, st));
+    ctx->n = n;
+    launch_jacobian_to_affine(st, d_jac, (uint32_t)n, ctx->d_table, d_prefix);
+    rc = build_tables(ctx, st, d_xyzz, d_prefix);
+    hipStreamDestroy(st);
+    hipFree(d_jac);
+    hipFree(d_prefix);
+    hipFree(d_xyzz);
+    if (rc) {
+        ctx->n = 0;
+        return rc;
+    }
+    return setup_slots(ctx);
+}
+
+int kzg_srs_generate_g1(kzg_ctx* ctx, const uint8_t secret_be[32], uint64_t first, size_t n) {
+    if (!ctx || !secret_be) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = srs_prepare(ctx, n);
+    if (rc) return rc;
+    uint32_t raw[8];
+    for (int w = 0; w < 8; w++) {
+        // big-endian bytes -> little-endian 32-bit words (reference src/trusted_setup.rs:24)
+        const uint8_t* b = secret_be + 28 - 4 * w;
+        raw[w] = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | (uint32_t)b[3];
+    }
+    size_t tmp_records = n > 32 * 255 ? n : 32 * 255;
+    void *d_gtable = nullptr, *d_prefix = nullptr, *d_xyzz = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_gtable, srs_gtable_bytes()));
+    HIP_TRY(ctx, hipMalloc(&d_prefix, tmp_records * 48));
+    HIP_TRY(ctx, hipMalloc(&d_xyzz, tmp_records * kXyzzBytes));
+    hipStream_t st = nullptr;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    ctx->n = n;
+    launch_srs_generate(st, raw, first, (uint32_t)n, d_gtable, d_xyzz, d_prefix, ctx->d_table);
+    rc = build_tables(ctx, st, d_xyzz, d_prefix);
+    hipStreamDestroy(st);
+    hipFree(d_gtable);
+    hipFree(d_prefix);
+    hipFree(d_xyzz);
+    if (rc) {
+        ctx->n = 0;
+        return rc;
+    }
+    return setup_slots(ctx);
+}
+
+int kzg_srs_read_g1(kzg_ctx* ctx, size_t index, size_t count, uint64_t* out_p1) {
+    if (!ctx || !out_p1) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->n) return KZG_ERR_NO_SRS;
+    if (index > ctx->n || count > ctx->n - index) return KZG_ERR_INVALID_ARG;
+    if (!count) return KZG_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    void* d_p1 = nullptr;
+    HIP_TRY(ctx, hipMalloc(&d_p1, count * 144));
+    hipStream_t st = ctx->slots[0].stream;
+    launch_affine_to_p1(st, (const char*)ctx->d_table + index * kAffineBytes, (uint32_t)count, d_p1);
+    HIP_TRY(ctx, hipMemcpyAsync(out_p1, d_p1, count * 144, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    hipFree(d_p1);
+    return KZG_OK;
+}
+
+// ---- submit / wait ---------------------------------------------------------------------------
+
+static int submit_commit_locked(kzg_ctx* ctx, int slot, const uint32_t* d_scalars, int is_mont, size_t n,
+                                bool tail_already_checked) {
+    if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
+    if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
+    Slot& s = ctx->slots[slot];
+    if (s.kind != SLOT_IDLE) return KZG_ERR_BUSY;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    s.timing = ctx->timing;
+    s.has_quotient = false;
+    s.job_n = n;
+    s.tail_checked = tail_already_checked;
+    std::memset(&s.times, 0, sizeof s.times);
+    size_t n_msm = n < ctx->n ? n : ctx->n;
+    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    if (n > ctx->n && !tail_already_checked) {
+        // reference: the Polynomial was truncated at construction (src/polynomial.rs:55-75), so only a
+        // non-zero coefficient beyond the SRS makes the degree too high (src/polynomial.rs:201-205)
+        uint64_t cnt = n - ctx->n;
+        hipLaunchKernelGGL(k_tail_nonzero, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s.stream, d_scalars,
+                           (uint64_t)ctx->n, (uint64_t)n, s.d_small + 24);
+    }
+    if (n_msm == 0) {
+        s.kind = SLOT_TRIVIAL;
+        return KZG_OK;
+    }
+    int rc = enqueue_msm(ctx, s, d_scalars, is_mont, n_msm, 0);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
+    s.kind = SLOT_COMMIT;
+    return KZG_OK;
+}
+
+int kzg_commit_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n) {
+    if (!ctx || (!d_coeffs && n)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return submit_commit_locked(ctx, slot, (const uint32_t*)d_coeffs, 1, n, false);
+}
+
+static int submit_open_locked(kzg_ctx* ctx, int slot, const uint32_t* d_coeffs, size_t n, const uint64_t z[4],
+                              const uint64_t y[4]) {
+    if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
+    if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
+    Slot& s = ctx->slots[slot];
+    if (s.kind != SLOT_IDLE) return KZG_ERR_BUSY;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_poly(ctx, s, n);
+    if (rc) return rc;
+    s.timing = ctx->timing;
+    s.job_n = n;
+    s.has_quotient = true;
+    s.tail_checked = false;
+    std::memcpy(s.open_y, y, 32);
+    std::memset(&s.times, 0, sizeof s.times);
+    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    if (n == 0) {
+        s.kind = SLOT_TRIVIAL;
+        return KZG_OK;
+    }
+    uint32_t zw[8];
+    std::memcpy(zw, z, 32);
+    PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
+    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[6], s.stream));
+    launch_quotient(s.stream, d_coeffs, (uint32_t)n, zw, n > 1 ? s.d_q : nullptr, sc);
+    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[7], s.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(s.d_small + 16, d_coeffs, 32, hipMemcpyDeviceToDevice, s.stream));  // c0
+    size_t nq = n - 1;
+    if (nq > ctx->n) {
+        // quotient longer than the SRS: too high iff some coefficient with index > srs_len is non-zero
+        uint64_t from = ctx->n + 1, cnt = n - from;
+        hipLaunchKernelGGL(k_tail_nonzero, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s.stream, d_coeffs, from,
+                           (uint64_t)n, s.d_small + 24);
+        nq = ctx->n;
+    }
+    if (nq > 0) {
+        rc = enqueue_msm(ctx, s, s.d_q, 1, nq, 0);
+        if (rc) return rc;
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
+    s.kind = nq > 0 ? SLOT_OPEN : SLOT_TRIVIAL;
+    return KZG_OK;
+}
+
+int kzg_open_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, const uint64_t z[4], const uint64_t y[4]) {
+    if (!ctx || !z || !y || (!d_coeffs && n)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return submit_open_locked(ctx, slot, (const uint32_t*)d_coeffs, n, z, y);
+}
+
+static int wait_locked(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
+    if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
+    Slot& s = ctx->slots[slot];
+    if (s.kind == SLOT_IDLE) return KZG_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    SlotKind kind = s.kind;
+    s.kind = SLOT_IDLE;
+    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    if (kind == SLOT_TRIVIAL)  // nothing but flags may have been enqueued
+        HIP_TRY(ctx, hipMemcpy(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost));
+    if (s.timing && kind != SLOT_TRIVIAL) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, s.ev[0], s.ev[1]); s.times.digits_ms = ms;
+        hipEventElapsedTime(&ms, s.ev[1], s.ev[2]); s.times.scan_ms = ms;
+        hipEventElapsedTime(&ms, s.ev[2], s.ev[3]); s.times.scatter_ms = ms;
+        hipEventElapsedTime(&ms, s.ev[3], s.ev[4]); s.times.accumulate_ms = ms;
+        hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;
+        if (s.has_quotient) {
+            hipEventElapsedTime(&ms, s.ev[6], s.ev[7]); s.times.quotient_ms = ms;
+            hipEventElapsedTime(&ms, s.ev[6], s.ev[5]); s.times.total_ms = ms;
+        } else {
+            hipEventElapsedTime(&ms, s.ev[0], s.ev[5]); s.times.total_ms = ms;
+        }
+    }
+    const uint32_t* hs = s.h_small;
+    hf::P1 inf = hf::p1_inf();
+    if (s.has_quotient) {
+        // reference order: sub -> divide_by_root (its two errors) -> commit (degree error)
+        const size_t n = s.job_n;
+        if (n == 0) {  // [] - [y]  (src/polynomial.rs:138-143)
+            bool y_zero = true;
+            for (int i = 0; i < 8; i++) y_zero &= s.open_y[i] == 0;
+            if (!y_zero) return KZG_ERR_CONSTANT_POLY;
+            write_p1(out_p1, inf);
+            return KZG_OK;
+        }
+        bool higher_nonzero = hs[0] & 1u;
+        if (!higher_nonzero) {  // constant polynomial after truncation (src/polynomial.rs:159-167)
+            if (std::memcmp(hs + 16, s.open_y, 32) != 0) return KZG_ERR_CONSTANT_POLY;
+            write_p1(out_p1, inf);
+            return KZG_OK;
+        }
+        if (std::memcmp(hs + 8, s.open_y, 32) != 0) return KZG_ERR_REMAINDER;  // P(z) != y
+        if (hs[24]) return KZG_ERR_DEGREE_TOO_HIGH;
+    } else {
+        if (hs[24]) return KZG_ERR_DEGREE_TOO_HIGH;
+    }
+    if (kind == SLOT_TRIVIAL) {
+        write_p1(out_p1, inf);
+        return KZG_OK;
+    }
+    write_p1(out_p1, finish_msm(ctx, s));
+    return KZG_OK;
+}
+
+int kzg_wait(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
+    if (!ctx || !out_p1) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return wait_locked(ctx, slot, out_p1);
+}
+
+// ---- synchronous host-pointer entry points (what the Rust shim calls) ---------------------------
+
+static int find_idle_slot(kzg_ctx* ctx) {
+    for (int i = 0; i < kNumSlots; i++)
+        if (ctx->slots[i].kind == SLOT_IDLE) return i;
+    return -1;
+}
+
+static int commit_host(kzg_ctx* ctx, const void* scalars, int is_mont, size_t n, uint64_t out_p1[18]) {
+    if (!ctx || !out_p1 || (!scalars && n)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
+    int slot = find_idle_slot(ctx);
+    if (slot < 0) return KZG_ERR_BUSY;
+    Slot& s = ctx->slots[slot];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (n > ctx->n && host_tail_nonzero((const uint64_t*)scalars, ctx->n, n)) return KZG_ERR_DEGREE_TOO_HIGH;
+    size_t n_dev = n < ctx->n ? n : ctx->n;
+    int rc = ensure_poly(ctx, s, n_dev);
+    if (rc) return rc;
+    if (n_dev) HIP_TRY(ctx, hipMemcpyAsync(s.d_stage, scalars, n_dev * 32, hipMemcpyHostToDevice, s.stream));
+    rc = submit_commit_locked(ctx, slot, s.d_stage, is_mont, n_dev, true);
+    if (rc) return rc;
+    return wait_locked(ctx, slot, out_p1);
+}
+
+int kzg_commit(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, uint64_t out_p1[18]) {
+    return commit_host(ctx, coeffs, 1, n, out_p1);
+}
+int kzg_commit_le_bytes(kzg_ctx* ctx, const uint8_t* scalars_le, size_t n, uint64_t out_p1[18]) {
+    return commit_host(ctx, scalars_le, 0, n, out_p1);
+}
+
+int kzg_open(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4], const uint64_t y[4],
+             uint64_t out_p1[18]) {
+    if (!ctx || !out_p1 || !z || !y || (!coeffs && n)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
+    int slot = find_idle_slot(ctx);
+    if (slot < 0) return KZG_ERR_BUSY;
+    Slot& s = ctx->slots[slot];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_poly(ctx, s, n);
+    if (rc) return rc;
+    if (n) HIP_TRY(ctx, hipMemcpyAsync(s.d_stage, coeffs, n * 32, hipMemcpyHostToDevice, s.stream));
+    rc = submit_open_locked(ctx, slot, s.d_stage, n, z, y);
+    if (rc) return rc;
+    return wait_locked(ctx, slot, out_p1);
+}
+
+int kzg_quotient(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4], const uint64_t y[4],
+                 uint64_t* out_q, size_t* out_qn) {
+    if (!ctx || !z || !y || !out_qn || (!coeffs && n) || (!out_q && n > 1)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    *out_qn = 0;
+    int slot = find_idle_slot(ctx);
+    if (slot < 0) return KZG_ERR_BUSY;
+    Slot& s = ctx->slots[slot];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!s.stream) {  // quotient does not need an SRS: make the slot usable on its own
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        for (auto& e : s.ev) HIP_TRY(ctx, hipEventCreate(&e));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        HIP_TRY(ctx, hipMalloc(&s.d_small, 64 * 4));
+        HIP_TRY(ctx, hipHostMalloc(&s.h_small, 64 * 4));
+    }
+    bool y_zero = (y[0] | y[1] | y[2] | y[3]) == 0;
+    if (n == 0) return y_zero ? KZG_OK : KZG_ERR_CONSTANT_POLY;
+    int rc = ensure_poly(ctx, s, n);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(s.d_stage, coeffs, n * 32, hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    uint32_t zw[8];
+    std::memcpy(zw, z, 32);
+    PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
+    launch_quotient(s.stream, s.d_stage, (uint32_t)n, zw, n > 1 ? s.d_q : nullptr, sc);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    bool higher_nonzero = s.h_small[0] & 1u;
+    if (!higher_nonzero) return std::memcmp(coeffs, y, 32) == 0 ? KZG_OK : KZG_ERR_CONSTANT_POLY;
+    if (std::memcmp(s.h_small + 8, y, 32) != 0) return KZG_ERR_REMAINDER;
+    // quotient of the truncated polynomial: its length is (index of the last non-zero coefficient)
+    size_t n_eff = n;
+    while (n_eff > 1 && !(coeffs[4 * (n_eff - 1)] | coeffs[4 * (n_eff - 1) + 1] | coeffs[4 * (n_eff - 1) + 2] |
+                          coeffs[4 * (n_eff - 1) + 3]))
+        n_eff--;
+    HIP_TRY(ctx, hipMemcpy(out_q, s.d_q, (n_eff - 1) * 32, hipMemcpyDeviceToHost));
+    *out_qn = n_eff - 1;
+    return KZG_OK;
+}
+
+int kzg_evaluate(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out_y[4]) {
+    if (!ctx || !z || !out_y || (!coeffs && n)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::memset(out_y, 0, 32);
+    if (n == 0) return KZG_OK;
+    int slot = find_idle_slot(ctx);
+    if (slot < 0) return KZG_ERR_BUSY;
+    Slot& s = ctx->slots[slot];
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!s.stream) {
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+        for (auto& e : s.ev) HIP_TRY(ctx, hipEventCreate(&e));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        HIP_TRY(ctx, hipMalloc(&s.d_small, 64 * 4));
+        HIP_TRY(ctx, hipHostMalloc(&s.h_small, 64 * 4));
+    }
+    int rc = ensure_poly(ctx, s, n);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(s.d_stage, coeffs, n * 32, hipMemcpyHostToDevice, s.stream));
+    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    uint32_t zw[8];
+    std::memcpy(zw, z, 32);
+    PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
+    launch_quotient(s.stream, s.d_stage, (uint32_t)n, zw, nullptr, sc);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    std::memcpy(out_y, s.h_small + 8, 32);
+    return KZG_OK;
+}
+
+// ---- raw device memory -----------------------------------------------------------------------
+
+int kzg_dev_alloc(kzg_ctx* ctx, size_t bytes, void** out) {
+    if (!ctx || !out) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(out, bytes ? bytes : 1));
+    return KZG_OK;
+}
+int kzg_dev_free(kzg_ctx* ctx, void* p) {
+    if (!ctx) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipFree(p));
+    return KZG_OK;
+}
+int kzg_dev_upload(kzg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return KZG_OK;
+}
+int kzg_dev_download(kzg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return KZG_OK;
+}
+
+// ---- host-side G1 helpers ----------------------------------------------------------------------
+
+int kzg_g1_sum(const uint64_t* p1s, size_t k, uint64_t out_p1[18]) {
+    if (!out_p1 || (!p1s && k)) return KZG_ERR_INVALID_ARG;
+    hf::P1 acc = hf::p1_inf();
+    for (size_t i = 0; i < k; i++) {
+        hf::P1 p;
+        std::memcpy(&p, p1s + 18 * i, sizeof p);
+        acc = hf::p1_add(acc, p);
+    }
+    write_p1(out_p1, hf::p1_normalize(acc));
+    return KZG_OK;
+}
+
+int kzg_g1_compress(const uint64_t p1[18], uint8_t out[48]) {
+    if (!p1 || !out) return KZG_ERR_INVALID_ARG;
+    hf::P1 p;
+    std::memcpy(&p, p1, sizeof p);
+    hf::p1_compress(out, p);
+    return KZG_OK;
+}
+
+// ---- measurement ---------------------------------------------------------------------------------
+
+int kzg_set_timing(kzg_ctx* ctx, int enabled) {
+    if (!ctx) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->timing = enabled != 0;
+    return KZG_OK;
+}
+int kzg_get_times(kzg_ctx* ctx, int slot, kzg_kernel_times* out) {
+    if (!ctx || !out || slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    *out = ctx->slots[slot].times;
+    return KZG_OK;
+}
+
+}  // extern "C"

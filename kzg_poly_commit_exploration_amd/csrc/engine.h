@@ -1,0 +1,78 @@
+// engine.h -- internal interface between the C-ABI (api.hip) and the kernel translation units.
+// Not installed; the public boundary is include/kzg_mi355x.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace kzg {
+
+// One affine SRS / table point in HBM: x then y, 12 + 12 little-endian u32 limbs, Montgomery.
+// 96 bytes, 16-byte aligned, (0,0) = infinity.  Table layout: window-major, T[j * n + i] =
+// 2^(c*j) * SRS[i]  (j < W), so window 0 is the SRS itself.
+constexpr size_t kAffineBytes = 96;
+// One XYZZ accumulator in HBM: X, Y, ZZ, ZZZ, 4 x 12 u32 = 192 bytes.
+constexpr size_t kXyzzBytes = 192;
+constexpr size_t kXyzzWords64 = 24;
+
+struct MsmConfig {
+    uint32_t c;   // window bits
+    uint32_t W;   // windows = ceil(256 / c)
+    uint32_t nb;  // buckets = 2^(c-1)  (signed digits, magnitude 1 .. 2^(c-1))
+};
+
+MsmConfig choose_msm_config(size_t n_points);
+
+// ---- msm_kernels.hip --------------------------------------------------------------------
+// pass 1: recode every scalar into W signed digits, histogram the buckets, remember each
+// (scalar, window) pair's arrival rank inside its bucket.
+void launch_digits_hist(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n,
+                        MsmConfig cfg, uint32_t* d_hist, uint32_t* d_rank);
+// exclusive prefix sum of the bucket histogram -> d_offs[0..nb] (d_offs[nb] = number of pairs)
+void launch_bucket_scan(hipStream_t s, const uint32_t* d_hist, uint32_t nb, uint32_t* d_offs,
+                        uint32_t* d_block_sums);
+// orders buckets by decreasing population so that the lanes of a wavefront run equally long
+void launch_bucket_order(hipStream_t s, const uint32_t* d_hist, uint32_t nb, uint32_t* d_count_hist,
+                         uint32_t* d_order);
+// pass 2: counting-sort scatter of (table index | sign << 31) into bucket-major order
+void launch_scatter(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n,
+                    uint32_t table_stride, MsmConfig cfg, const uint32_t* d_offs, const uint32_t* d_rank,
+                    uint32_t* d_sorted);
+// bucket accumulation (dominant kernel): one lane per bucket, XYZZ += affine table point
+void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted,
+                              const uint32_t* d_offs, const uint32_t* d_order, uint32_t nb, void* d_buckets);
+// one level of the weighted running-sum reduction over `n_items` XYZZ items in chunks of m:
+//   acc[k] = sum_{t<m} (t+1) * in[k*m + t],   run[k] = sum_{t<m} in[k*m + t]
+void launch_wsum_level(hipStream_t s, const void* d_in, uint32_t n_items, uint32_t m, void* d_acc, void* d_run);
+// plain chunk sums: out[k] = sum_{t<m} in[k*m + t]
+void launch_sum_level(hipStream_t s, const void* d_in, uint32_t n_items, uint32_t m, void* d_out);
+
+// ---- srs_kernels.hip --------------------------------------------------------------------
+// blst_p1 Jacobian (host layout, strided) already copied to d_jac (n x 144 B contiguous) -> affine
+void launch_jacobian_to_affine(hipStream_t s, const void* d_jac, uint32_t n, void* d_affine_out,
+                               void* d_prefix_tmp);
+// table window j from window j-1:  T[j][i] = 2^c * T[j-1][i]
+void launch_table_window(hipStream_t s, const void* d_prev_affine, uint32_t n, uint32_t c,
+                         void* d_xyzz_tmp, void* d_prefix_tmp, void* d_next_affine);
+// fixed-base trusted setup: out[i] = [s^(first+i)] G1, affine
+void launch_srs_generate(hipStream_t s, const uint32_t* secret_raw8 /* 256-bit LE integer */, uint64_t first, uint32_t n,
+                         void* d_gtable, void* d_xyzz_tmp, void* d_prefix_tmp, void* d_affine_out);
+size_t srs_gtable_bytes();
+// affine table entries -> blst_p1 (Z = Montgomery one / all zero for infinity)
+void launch_affine_to_p1(hipStream_t s, const void* d_affine, uint32_t n, void* d_p1_out);
+
+// ---- poly_kernels.hip -------------------------------------------------------------------
+struct PolyScratch {
+    uint32_t* d_chunk;   // per-thread chunk values / carries (Fr)
+    uint32_t* d_block;   // per-block aggregates (Fr)
+    uint32_t* d_flags;   // [0] = any non-zero coefficient with index >= 1
+    uint32_t* d_result;  // P(z) (8 words)
+};
+size_t poly_chunk_words(uint32_t n);
+size_t poly_block_words(uint32_t n);
+// suffix Horner scan S[i] = sum_{k>=i} c[k] z^(k-i):  q[i-1] = S[i] (i >= 1) when d_q != nullptr,
+// P(z) = S[0] to scratch.d_result; flags as above.  z in Montgomery form (8 words, host copy).
+void launch_quotient(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const uint32_t z_mont[8],
+                     uint32_t* d_q, PolyScratch scratch);
+
+}  // namespace kzg

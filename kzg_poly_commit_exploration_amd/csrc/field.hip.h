@@ -263,10 +263,10 @@ typedef Fe<FrParams> Fr;
 // The group law's rare branches (doubling when a bucket receives the point it already holds)
 // must not set the register budget of the hot loop, so they run on small non-unrolled routines
 // that work on arrays in private memory.  Slow by design; bit-identical results.
-__device__ const u32 KZG_FP_MOD[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+static __device__ const u32 KZG_FP_MOD[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
                                        0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
 
-__device__ __noinline__ void fp_rolled_condsub(u32* t, u32 top) {
+static __device__ __noinline__ void fp_rolled_condsub(u32* t, u32 top) {
     u32 d[12];
     u32 br = 0;
 #pragma unroll 1
@@ -280,7 +280,7 @@ __device__ __noinline__ void fp_rolled_condsub(u32* t, u32 top) {
         for (int i = 0; i < 12; i++) t[i] = d[i];
     }
 }
-__device__ __noinline__ void fp_rolled_mul(u32* r, const u32* a, const u32* b) {
+static __device__ __noinline__ void fp_rolled_mul(u32* r, const u32* a, const u32* b) {
     u32 t[14];
 #pragma unroll 1
     for (int i = 0; i < 14; i++) t[i] = 0;
@@ -313,7 +313,7 @@ __device__ __noinline__ void fp_rolled_mul(u32* r, const u32* a, const u32* b) {
 #pragma unroll 1
     for (int i = 0; i < 12; i++) r[i] = t[i];
 }
-__device__ __noinline__ void fp_rolled_add(u32* r, const u32* a, const u32* b) {
+static __device__ __noinline__ void fp_rolled_add(u32* r, const u32* a, const u32* b) {
     u32 t[12];
     u64 c = 0;
 #pragma unroll 1
@@ -326,7 +326,7 @@ __device__ __noinline__ void fp_rolled_add(u32* r, const u32* a, const u32* b) {
 #pragma unroll 1
     for (int i = 0; i < 12; i++) r[i] = t[i];
 }
-__device__ __noinline__ void fp_rolled_sub(u32* r, const u32* a, const u32* b) {
+static __device__ __noinline__ void fp_rolled_sub(u32* r, const u32* a, const u32* b) {
     u32 t[12];
     u32 br = 0;
 #pragma unroll 1

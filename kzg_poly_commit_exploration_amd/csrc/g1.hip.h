@@ -13,6 +13,17 @@ namespace kzg {
 
 #define KZG_SB() __builtin_amdgcn_sched_barrier(0)
 
+// Fp products of the group law go through fmul/fsqr.  With KZG_MUL_CALL they are real function
+// calls (one copy of the ~1000-instruction multiplier in the instruction cache instead of ten per
+// addition); otherwise they are inlined.  Chosen per kernel from measurements.
+#ifdef KZG_MUL_CALL
+static __device__ __noinline__ Fp fmul(Fp a, Fp b) { return fe_mul(a, b); }
+static __device__ __noinline__ Fp fsqr(Fp a) { return fe_mul(a, a); }
+#else
+KZG_DEV Fp fmul(const Fp& a, const Fp& b) { return fe_mul(a, b); }
+KZG_DEV Fp fsqr(const Fp& a) { return fe_mul(a, a); }
+#endif
+
 struct Affine {  // Montgomery x, y;  (0, 0) encodes the point at infinity (it is not on the curve)
     Fp x, y;
     KZG_DEV bool is_inf() const {
@@ -51,31 +62,31 @@ KZG_DEV XYZZ xyzz_dbl(const XYZZ& a) {
     if (a.is_inf() || a.Y.is_zero()) return XYZZ::inf();
     XYZZ r;
     Fp U = fe_dbl(a.Y);
-    Fp V = fe_sqr(U);
+    Fp V = fsqr(U);
     KZG_SB();
-    Fp W = fe_mul(U, V);
+    Fp W = fmul(U, V);
     KZG_SB();
-    Fp S = fe_mul(a.X, V);
+    Fp S = fmul(a.X, V);
     KZG_SB();
-    r.ZZ = fe_mul(V, a.ZZ);
+    r.ZZ = fmul(V, a.ZZ);
     KZG_SB();
-    Fp M = fe_sqr(a.X);
+    Fp M = fsqr(a.X);
     KZG_SB();
     M = fe_add(fe_dbl(M), M);
-    r.X = fe_sub(fe_sub(fe_sqr(M), S), S);
+    r.X = fe_sub(fe_sub(fsqr(M), S), S);
     KZG_SB();
-    r.ZZZ = fe_mul(W, a.ZZZ);
+    r.ZZZ = fmul(W, a.ZZZ);
     KZG_SB();
-    Fp WY = fe_mul(W, a.Y);
+    Fp WY = fmul(W, a.Y);
     KZG_SB();
-    r.Y = fe_sub(fe_mul(M, fe_sub(S, r.X)), WY);
+    r.Y = fe_sub(fmul(M, fe_sub(S, r.X)), WY);
     KZG_SB();
     return r;
 }
 
 // 2 * a on the rolled routines (exceptional branch of the additions: equal operands).
 // io = {X, Y, ZZ, ZZZ} as 4 x 12 words in private memory, overwritten with the double.
-__device__ __noinline__ void xyzz_dbl_rare(u32* io) {
+static __device__ __noinline__ void xyzz_dbl_rare(u32* io) {
     u32 *X = io, *Y = io + 12, *ZZ = io + 24, *ZZZ = io + 36;
     u32 U[12], V[12], W[12], S[12], M[12], T[12];
     fp_rolled_add(U, Y, Y);
@@ -135,9 +146,9 @@ KZG_DEV void xyzz_madd(XYZZ& acc, const Affine& p_in, bool neg) {
         acc.ZZZ = Fp::one();
         return;
     }
-    Fp P = fe_sub(fe_mul(p_in.x, acc.ZZ), acc.X);  // U2 - X1
+    Fp P = fe_sub(fmul(p_in.x, acc.ZZ), acc.X);  // U2 - X1
     KZG_SB();
-    Fp R = fe_sub(fe_mul(py, acc.ZZZ), acc.Y);  // S2 - Y1
+    Fp R = fe_sub(fmul(py, acc.ZZZ), acc.Y);  // S2 - Y1
     KZG_SB();
     if (P.is_zero()) {
         if (R.is_zero()) {
@@ -147,21 +158,21 @@ KZG_DEV void xyzz_madd(XYZZ& acc, const Affine& p_in, bool neg) {
         }
         return;
     }
-    Fp PP = fe_sqr(P);
+    Fp PP = fsqr(P);
     KZG_SB();
-    acc.ZZ = fe_mul(acc.ZZ, PP);
+    acc.ZZ = fmul(acc.ZZ, PP);
     KZG_SB();
-    Fp Q = fe_mul(acc.X, PP);
+    Fp Q = fmul(acc.X, PP);
     KZG_SB();
-    Fp PPP = fe_mul(P, PP);
+    Fp PPP = fmul(P, PP);
     KZG_SB();
-    acc.ZZZ = fe_mul(acc.ZZZ, PPP);
+    acc.ZZZ = fmul(acc.ZZZ, PPP);
     KZG_SB();
-    Fp YP = fe_mul(acc.Y, PPP);
+    Fp YP = fmul(acc.Y, PPP);
     KZG_SB();
-    Fp X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    Fp X3 = fe_sub(fe_sub(fsqr(R), PPP), fe_dbl(Q));
     KZG_SB();
-    acc.Y = fe_sub(fe_mul(R, fe_sub(Q, X3)), YP);
+    acc.Y = fe_sub(fmul(R, fe_sub(Q, X3)), YP);
     acc.X = X3;
     KZG_SB();
 }
@@ -173,37 +184,42 @@ KZG_DEV void xyzz_add(XYZZ& acc, const XYZZ& b) {
         acc = b;
         return;
     }
-    Fp U1 = fe_mul(acc.X, b.ZZ);
+    Fp U1 = fmul(acc.X, b.ZZ);
     KZG_SB();
-    Fp P = fe_sub(fe_mul(b.X, acc.ZZ), U1);
+    Fp P = fe_sub(fmul(b.X, acc.ZZ), U1);
     KZG_SB();
-    Fp S1 = fe_mul(acc.Y, b.ZZZ);
+    Fp S1 = fmul(acc.Y, b.ZZZ);
     KZG_SB();
-    Fp R = fe_sub(fe_mul(b.Y, acc.ZZZ), S1);
+    Fp R = fe_sub(fmul(b.Y, acc.ZZZ), S1);
     KZG_SB();
     if (P.is_zero()) {
         if (R.is_zero()) {
+            // equal operands: frequent in the running-sum reduction when buckets are empty
+#ifdef KZG_FAST_DBL_IN_ADD
+            acc = xyzz_dbl(acc);
+#else
             xyzz_dbl_inplace_rare(acc);
+#endif
         } else {
             acc = XYZZ::inf();
         }
         return;
     }
-    Fp PP = fe_sqr(P);
+    Fp PP = fsqr(P);
     KZG_SB();
-    acc.ZZ = fe_mul(fe_mul(acc.ZZ, b.ZZ), PP);
+    acc.ZZ = fmul(fmul(acc.ZZ, b.ZZ), PP);
     KZG_SB();
-    Fp Q = fe_mul(U1, PP);
+    Fp Q = fmul(U1, PP);
     KZG_SB();
-    Fp PPP = fe_mul(P, PP);
+    Fp PPP = fmul(P, PP);
     KZG_SB();
-    acc.ZZZ = fe_mul(fe_mul(acc.ZZZ, b.ZZZ), PPP);
+    acc.ZZZ = fmul(fmul(acc.ZZZ, b.ZZZ), PPP);
     KZG_SB();
-    Fp YP = fe_mul(S1, PPP);
+    Fp YP = fmul(S1, PPP);
     KZG_SB();
-    Fp X3 = fe_sub(fe_sub(fe_sqr(R), PPP), fe_dbl(Q));
+    Fp X3 = fe_sub(fe_sub(fsqr(R), PPP), fe_dbl(Q));
     KZG_SB();
-    acc.Y = fe_sub(fe_mul(R, fe_sub(Q, X3)), YP);
+    acc.Y = fe_sub(fmul(R, fe_sub(Q, X3)), YP);
     acc.X = X3;
     KZG_SB();
 }
@@ -214,8 +230,8 @@ KZG_DEV XYZZ xyzz_from_jacobian(const Fp& X, const Fp& Y, const Fp& Z) {
     if (Z.is_zero()) return XYZZ::inf();
     r.X = X;
     r.Y = Y;
-    r.ZZ = fe_sqr(Z);
-    r.ZZZ = fe_mul(r.ZZ, Z);
+    r.ZZ = fsqr(Z);
+    r.ZZZ = fmul(r.ZZ, Z);
     return r;
 }
 
@@ -230,8 +246,8 @@ KZG_DEV void xyzz_to_jacobian(const XYZZ& a, Fp& X, Fp& Y, Fp& Z) {
         Z = Fp::zero();
         return;
     }
-    X = fe_mul(a.X, a.ZZ);
-    Y = fe_mul(a.Y, a.ZZZ);
+    X = fmul(a.X, a.ZZ);
+    Y = fmul(a.Y, a.ZZZ);
     Z = a.ZZ;
 }
 

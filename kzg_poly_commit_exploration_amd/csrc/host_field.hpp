@@ -1,0 +1,201 @@
+// host_field.hpp -- host-side Fp / G1 arithmetic of the PRODUCT library (not the oracle).
+//
+// The device reduces an MSM to a few dozen partial sums; the host finishes the job the way the
+// reference's caller would with blst on the CPU: a handful of complete point additions
+// (blst_p1_add_or_double, reference src/curves.rs:79-85), one inversion to normalise, and the
+// ZCash compression the reference's serde emits (src/curves.rs:99-110).  A single GPU lane needs
+// ~1 us per 381-bit multiplication, a host core ~40 ns, so this serial tail belongs here.
+// Also used for the multi-GPU combine of the RCCL-gathered partial sums.
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+namespace kzg_host {
+
+typedef unsigned __int128 u128;
+
+struct Fp {
+    uint64_t l[6];
+    bool is_zero() const { return (l[0] | l[1] | l[2] | l[3] | l[4] | l[5]) == 0; }
+    bool operator==(const Fp& o) const { return std::memcmp(l, o.l, sizeof l) == 0; }
+};
+
+static const Fp kP = {{0xb9feffffffffaaabULL, 0x1eabfffeb153ffffULL, 0x6730d2a0f6b0f624ULL,
+                       0x64774b84f38512bfULL, 0x4b1ba7b6434bacd7ULL, 0x1a0111ea397fe69aULL}};
+static const Fp kOne = {{0x760900000002fffdULL, 0xebf4000bc40c0002ULL, 0x5f48985753c758baULL,
+                         0x77ce585370525745ULL, 0x5c071a97a256ec6dULL, 0x15f65ec3fa80e493ULL}};
+static const uint64_t kN0 = 0x89f3fffcfffcfffdULL;
+static const Fp kHalf = {{0xdcff7fffffffd555ULL, 0x0f55ffff58a9ffffULL, 0xb39869507b587b12ULL,
+                          0xb23ba5c279c2895fULL, 0x258dd3db21a5d66bULL, 0x0d0088f51cbff34dULL}};
+
+inline bool geq(const Fp& a, const Fp& b) {
+    for (int i = 5; i >= 0; --i)
+        if (a.l[i] != b.l[i]) return a.l[i] > b.l[i];
+    return true;
+}
+inline Fp raw_sub(const Fp& a, const Fp& b, uint64_t& borrow) {
+    Fp r;
+    borrow = 0;
+    for (int i = 0; i < 6; ++i) {
+        u128 d = (u128)a.l[i] - b.l[i] - borrow;
+        r.l[i] = (uint64_t)d;
+        borrow = (uint64_t)(d >> 64) & 1;
+    }
+    return r;
+}
+inline Fp raw_add(const Fp& a, const Fp& b) {
+    Fp r;
+    u128 c = 0;
+    for (int i = 0; i < 6; ++i) {
+        c += (u128)a.l[i] + b.l[i];
+        r.l[i] = (uint64_t)c;
+        c >>= 64;
+    }
+    return r;
+}
+inline Fp operator+(const Fp& a, const Fp& b) {
+    Fp s = raw_add(a, b);
+    uint64_t br;
+    return geq(s, kP) ? raw_sub(s, kP, br) : s;
+}
+inline Fp operator-(const Fp& a, const Fp& b) {
+    uint64_t br;
+    Fp d = raw_sub(a, b, br);
+    return br ? raw_add(d, kP) : d;
+}
+inline Fp neg(const Fp& a) {
+    uint64_t br;
+    return a.is_zero() ? a : raw_sub(kP, a, br);
+}
+// Separated operand-scanning product followed by a word-by-word Montgomery reduction (REDC).
+inline Fp operator*(const Fp& a, const Fp& b) {
+    uint64_t w[13] = {0};
+    uint64_t hi_carry = 0;
+    for (int i = 0; i < 6; ++i) {
+        u128 c = 0;
+        for (int j = 0; j < 6; ++j) {
+            c += (u128)a.l[j] * b.l[i] + w[i + j];
+            w[i + j] = (uint64_t)c;
+            c >>= 64;
+        }
+        w[i + 6] = (uint64_t)c;
+    }
+    for (int i = 0; i < 6; ++i) {
+        uint64_t m = w[i] * kN0;
+        u128 c = 0;
+        for (int j = 0; j < 6; ++j) {
+            c += (u128)m * kP.l[j] + w[i + j];
+            w[i + j] = (uint64_t)c;
+            c >>= 64;
+        }
+        // propagate into the upper words
+        for (int k = i + 6; c != 0 && k < 12; ++k) {
+            c += w[k];
+            w[k] = (uint64_t)c;
+            c >>= 64;
+        }
+        hi_carry += (uint64_t)c;
+    }
+    Fp r;
+    for (int i = 0; i < 6; ++i) r.l[i] = w[6 + i];
+    uint64_t br;
+    if (hi_carry || geq(r, kP)) r = raw_sub(r, kP, br);
+    return r;
+}
+inline Fp sqr(const Fp& a) { return a * a; }
+inline Fp inv(const Fp& a) {  // a^(p-2)
+    Fp e = kP;
+    e.l[0] -= 2;
+    Fp acc = kOne, base = a;
+    for (int i = 0; i < 381; ++i) {
+        if ((e.l[i >> 6] >> (i & 63)) & 1) acc = acc * base;
+        base = sqr(base);
+    }
+    return acc;
+}
+inline Fp from_mont(const Fp& a) {
+    Fp one = {{1, 0, 0, 0, 0, 0}};
+    return a * one;
+}
+
+struct P1 {  // blst_p1 layout: Jacobian, Montgomery, z == 0 <=> infinity
+    Fp x, y, z;
+    bool is_inf() const { return z.is_zero(); }
+};
+static_assert(sizeof(P1) == 144, "blst_p1 is 18 x u64");
+
+inline P1 p1_inf() {
+    P1 r;
+    std::memset(&r, 0, sizeof r);
+    return r;
+}
+inline P1 p1_double(const P1& p) {
+    if (p.is_inf() || p.y.is_zero()) return p1_inf();
+    Fp A = sqr(p.x), B = sqr(p.y), C = sqr(B);
+    Fp t = sqr(p.x + B) - A - C;
+    Fp D = t + t;
+    Fp E = A + A + A;
+    Fp F = sqr(E);
+    P1 r;
+    r.x = F - D - D;
+    Fp C8 = C + C;
+    C8 = C8 + C8;
+    C8 = C8 + C8;
+    r.y = E * (D - r.x) - C8;
+    Fp yz = p.y * p.z;
+    r.z = yz + yz;
+    return r;
+}
+inline P1 p1_add(const P1& a, const P1& b) {  // complete: handles inf, a == b, a == -b
+    if (a.is_inf()) return b;
+    if (b.is_inf()) return a;
+    Fp z1z1 = sqr(a.z), z2z2 = sqr(b.z);
+    Fp u1 = a.x * z2z2, u2 = b.x * z1z1;
+    Fp s1 = a.y * b.z * z2z2, s2 = b.y * a.z * z1z1;
+    Fp h = u2 - u1, rr = s2 - s1;
+    if (h.is_zero()) return rr.is_zero() ? p1_double(a) : p1_inf();
+    Fp hh = sqr(h), hhh = h * hh, v = u1 * hh;
+    P1 r;
+    r.x = sqr(rr) - hhh - v - v;
+    r.y = rr * (v - r.x) - s1 * hhh;
+    r.z = a.z * b.z * h;
+    return r;
+}
+inline P1 p1_normalize(const P1& p) {  // affine with z = R (Montgomery one), or all-zero for inf
+    if (p.is_inf()) return p1_inf();
+    Fp zi = inv(p.z), zi2 = sqr(zi);
+    P1 r;
+    r.x = p.x * zi2;
+    r.y = p.y * zi2 * zi;
+    r.z = kOne;
+    return r;
+}
+// device XYZZ partial sum (X, Y, ZZ, ZZZ as 4 x 6 u64) -> Jacobian with Z = ZZ: X*ZZ, Y*ZZZ, ZZ
+inline P1 p1_from_xyzz(const uint64_t* w) {
+    Fp X, Y, ZZ, ZZZ;
+    std::memcpy(X.l, w, 48);
+    std::memcpy(Y.l, w + 6, 48);
+    std::memcpy(ZZ.l, w + 12, 48);
+    std::memcpy(ZZZ.l, w + 18, 48);
+    if (ZZ.is_zero()) return p1_inf();
+    P1 r;
+    r.x = X * ZZ;
+    r.y = Y * ZZZ;
+    r.z = ZZ;
+    return r;
+}
+inline void p1_compress(uint8_t out[48], const P1& p) {  // ZCash encoding (reference src/curves.rs:99-110)
+    if (p.is_inf()) {
+        std::memset(out, 0, 48);
+        out[0] = 0xC0;
+        return;
+    }
+    P1 a = p1_normalize(p);
+    Fp x = from_mont(a.x), y = from_mont(a.y);
+    for (int i = 0; i < 6; ++i)
+        for (int k = 0; k < 8; ++k) out[47 - (8 * i + k)] = (uint8_t)(x.l[i] >> (8 * k));
+    out[0] |= 0x80;
+    if (!(y == kHalf) && geq(y, kHalf)) out[0] |= 0x20;
+}
+
+}  // namespace kzg_host

@@ -1,0 +1,215 @@
+// poly_kernels.hip -- scalar-field synthetic division as a parallel suffix scan.
+//
+// Restates Polynomial::divide_by_root (reference src/polynomial.rs:150-195) on (P - y)
+// (src/polynomial.rs:128-145): the reference's sequential recurrence  q[i-1] = c[i] + z q[i]
+// is the suffix Horner scan
+//        S[i] = sum_{k >= i} c[k] z^(k-i),     q[i-1] = S[i]  (i >= 1),     S[0] = P(z),
+// and its final check  -z q[0] == c[0] - y  is  P(z) == y.  Subtracting y only changes c[0], which
+// no S[i >= 1] reads, so the same scan serves Polynomial::evaluate (src/polynomial.rs:112-123).
+//
+// Three launches over chunks of L coefficients per lane (coefficients past n count as zero):
+//   1. chunk Horner values, then a Kogge-Stone suffix scan inside the workgroup (multipliers
+//      z^(L 2^s), one Fr product per step), workgroup aggregates out;
+//   2. one workgroup scans the aggregates (multiplier z^(L*256));
+//   3. every lane replays its chunk from its now-known carry and writes q.
+// Algorithmic bytes: 32 B read + 32 B written per coefficient; the chunk
+// is read twice (the second time mostly from L2 / Infinity Cache).  HBM / latency bound.
+#include "engine.h"
+#include "field.hip.h"
+
+namespace kzg {
+
+constexpr int kPolyL = 8;        // coefficients per lane
+constexpr int kPolyBlock = 256;  // lanes per workgroup
+constexpr int kPolyTile = kPolyL * kPolyBlock;
+
+size_t poly_chunk_words(uint32_t n) { return ((size_t)(n + kPolyTile - 1) / kPolyTile) * kPolyBlock * 8; }
+size_t poly_block_words(uint32_t n) { return ((size_t)(n + kPolyTile - 1) / kPolyTile + 1) * 8; }
+
+KZG_DEV Fr load_fr(const uint32_t* __restrict__ p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 lo = q[0], hi = q[1];
+    Fr a;
+    a.l[0] = lo.x; a.l[1] = lo.y; a.l[2] = lo.z; a.l[3] = lo.w;
+    a.l[4] = hi.x; a.l[5] = hi.y; a.l[6] = hi.z; a.l[7] = hi.w;
+    return a;
+}
+KZG_DEV void store_fr(uint32_t* __restrict__ p, const Fr& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
+    q[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
+}
+struct FrArg {
+    uint32_t l[8];
+};
+KZG_DEV Fr fr_from_arg(const FrArg& a) {
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = a.l[i];
+    return r;
+}
+KZG_DEV Fr fr_pow_u32(Fr base, uint32_t e) {
+    Fr acc = Fr::one();
+    while (e) {
+        if (e & 1u) acc = fe_mul(acc, base);
+        base = fe_mul(base, base);
+        e >>= 1;
+    }
+    return acc;
+}
+
+// Kogge-Stone suffix scan over the workgroup: v_t <- sum_{u >= t} v_u * mult^(u - t)
+template <int BLOCK>
+KZG_DEV Fr block_suffix_scan(Fr v, Fr mult, uint32_t* lds /* BLOCK * 8 words */) {
+    const int t = threadIdx.x;
+    for (int off = 1; off < BLOCK; off <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) lds[i * BLOCK + t] = v.l[i];
+        __syncthreads();
+        if (t + off < BLOCK) {
+            Fr o;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o.l[i] = lds[i * BLOCK + t + off];
+            v = fe_add(v, fe_mul(mult, o));
+        }
+        __syncthreads();
+        mult = fe_mul(mult, mult);
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(kPolyBlock) k_poly_chunks(const uint32_t* __restrict__ coeffs, uint32_t n, FrArg zarg,
+                                                            uint32_t* __restrict__ d_chunk,
+                                                            uint32_t* __restrict__ d_block,
+                                                            uint32_t* __restrict__ d_flags) {
+    __shared__ uint32_t lds[kPolyBlock * 8];
+    const Fr z = fr_from_arg(zarg);
+    const uint32_t t = blockIdx.x * kPolyBlock + threadIdx.x;
+    const uint32_t base = t * kPolyL;
+    Fr h = Fr::zero();
+    bool nz = false;
+#pragma unroll 1
+    for (int k = kPolyL - 1; k >= 0; k--) {
+        uint32_t idx = base + k;
+        h = fe_mul(h, z);
+        if (idx < n) {
+            Fr c = load_fr(coeffs + (size_t)idx * 8);
+            if (idx >= 1 && !c.is_zero()) nz = true;
+            h = fe_add(h, c);
+        }
+    }
+    if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&d_flags[0], 1u);
+    Fr zl = fr_pow_u32(z, kPolyL);
+    h = block_suffix_scan<kPolyBlock>(h, zl, lds);
+    store_fr(d_chunk + (size_t)t * 8, h);
+    if (threadIdx.x == 0) store_fr(d_block + (size_t)blockIdx.x * 8, h);
+}
+
+// single workgroup: carries for every block.  d_block[b] in: aggregate of block b (zero carry-in);
+// out: d_block[b] = S at the first coefficient of block b+1 (its carry-in); d_result = P(z).
+__global__ void __launch_bounds__(1024) k_poly_blocks(uint32_t* __restrict__ d_block, uint32_t nblocks, FrArg zarg,
+                                                      uint32_t* __restrict__ d_result) {
+    __shared__ uint32_t lds[1024 * 8];
+    __shared__ uint32_t s_carry[8];
+    const Fr z = fr_from_arg(zarg);
+    const Fr zb = fr_pow_u32(z, kPolyTile);
+    const int t = threadIdx.x;
+    if (t < 8) s_carry[t] = 0;
+    __syncthreads();
+    // tiles of 1024 blocks, from the top of the polynomial down
+    uint32_t ntiles = (nblocks + 1023) / 1024;
+    for (uint32_t tile = ntiles; tile-- > 0;) {
+        uint32_t b = tile * 1024 + t;
+        Fr v = b < nblocks ? load_fr(d_block + (size_t)b * 8) : Fr::zero();
+        v = block_suffix_scan<1024>(v, zb, lds);
+        // add the carry from the tiles above: zb^(1024 - t) * carry
+        Fr carry;
+#pragma unroll
+        for (int i = 0; i < 8; i++) carry.l[i] = s_carry[i];
+        Fr full = fe_add(v, fe_mul(fr_pow_u32(zb, 1024 - t), carry));
+        // full = S at the start of block b.  carry-in of block b is S at the start of block b+1.
+#pragma unroll
+        for (int i = 0; i < 8; i++) lds[i * 1024 + t] = full.l[i];
+        __syncthreads();
+        Fr next;
+        if (t + 1 < 1024) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) next.l[i] = lds[i * 1024 + t + 1];
+        } else {
+            next = carry;
+        }
+        if (b < nblocks) store_fr(d_block + (size_t)b * 8, next);
+        __syncthreads();
+        if (t == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) s_carry[i] = full.l[i];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+        Fr r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = s_carry[i];
+        store_fr(d_result, r);
+    }
+}
+
+__global__ void __launch_bounds__(kPolyBlock) k_poly_apply(const uint32_t* __restrict__ coeffs, uint32_t n, FrArg zarg,
+                                                           const uint32_t* __restrict__ d_chunk,
+                                                           const uint32_t* __restrict__ d_block,
+                                                           uint32_t* __restrict__ d_q) {
+    __shared__ uint32_t s_pow[2][16][8];  // zl^(16a), zl^b
+    const Fr z = fr_from_arg(zarg);
+    const int tl = threadIdx.x;
+    const uint32_t t = blockIdx.x * kPolyBlock + tl;
+    if (tl < 32) {
+        Fr zl = fr_pow_u32(z, kPolyL);
+        int which = tl >> 4, e = tl & 15;
+        Fr p = fr_pow_u32(zl, which == 0 ? 16u * e : (uint32_t)e);
+#pragma unroll
+        for (int i = 0; i < 8; i++) s_pow[which][e][i] = p.l[i];
+    }
+    __syncthreads();
+    // carry into this lane's chunk = S at the first coefficient of the next chunk
+    Fr blk_carry = load_fr(d_block + (size_t)blockIdx.x * 8);
+    Fr h;
+    uint32_t dist = (uint32_t)(kPolyBlock - 1 - tl);  // chunks between the next chunk and the block end
+    Fr pa, pb;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        pa.l[i] = s_pow[0][dist >> 4][i];
+        pb.l[i] = s_pow[1][dist & 15][i];
+    }
+    Fr scaled = fe_mul(fe_mul(pa, pb), blk_carry);
+    if (tl + 1 < kPolyBlock) {
+        h = fe_add(load_fr(d_chunk + (size_t)(t + 1) * 8), scaled);
+    } else {
+        h = scaled;  // dist == 0: the block carry itself
+    }
+    const uint32_t base = t * kPolyL;
+#pragma unroll 1
+    for (int k = kPolyL - 1; k >= 0; k--) {
+        uint32_t idx = base + k;
+        h = fe_mul(h, z);
+        if (idx < n) {
+            h = fe_add(h, load_fr(coeffs + (size_t)idx * 8));
+            if (idx >= 1) store_fr(d_q + (size_t)(idx - 1) * 8, h);
+        }
+    }
+}
+
+void launch_quotient(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const uint32_t z_mont[8], uint32_t* d_q,
+                     PolyScratch sc) {
+    if (n == 0) return;
+    FrArg z;
+    for (int i = 0; i < 8; i++) z.l[i] = z_mont[i];
+    uint32_t nblocks = (n + kPolyTile - 1) / kPolyTile;
+    hipLaunchKernelGGL(k_poly_chunks, dim3(nblocks), dim3(kPolyBlock), 0, s, d_coeffs, n, z, sc.d_chunk, sc.d_block,
+                       sc.d_flags);
+    hipLaunchKernelGGL(k_poly_blocks, dim3(1), dim3(1024), 0, s, sc.d_block, nblocks, z, sc.d_result);
+    if (d_q && n > 1)
+        hipLaunchKernelGGL(k_poly_apply, dim3(nblocks), dim3(kPolyBlock), 0, s, d_coeffs, n, z, sc.d_chunk, sc.d_block,
+                           d_q);
+}
+
+}  // namespace kzg

@@ -1,0 +1,349 @@
+"""GPU parity tests: every call goes through the C-ABI (ctypes -> libkzg_mi355x.so -> HIP kernels)
+and is compared, as 48-byte compressed G1 encodings (reference src/curves.rs:99-110) or Fr values,
+against the CPU oracle on the same inputs and against tests/golden/golden.json.  Bit-exact: this is
+integer work, there is no tolerance.  Shapes follow the reference's own round-trip tests
+(src/lib.rs:16-33, 51-94) and benches (benches/polynomial_commitment.rs, evaluation_proof.rs)."""
+import random
+
+import numpy as np
+import pytest
+
+import kzg_poly_commit_exploration_amd as K
+
+pytestmark = pytest.mark.gpu
+
+SMALL_N = 2501  # covers the reference's bench degrees [1, 100, 500, 1000, 2500]
+
+
+def _bench_poly(oracle, degree):
+    c = oracle.bench_coefficients(degree + 1)
+    z = oracle.bench_input_point(degree)
+    y = oracle.poly_evaluate(c, z)
+    return c, K.Scalar.from_limbs(z), K.Scalar.from_limbs(y)
+
+
+def _case(golden, degree):
+    return next(b for b in golden["bench"] if b["degree"] == degree)
+
+
+# ---------------------------------------------------------------- SRS
+
+def test_srs_generation_matches_trusted_setup(engines, oracle, golden):
+    eng = engines.bench_srs(SMALL_N)
+    assert eng.srs_len() == SMALL_N
+    secret = bytes.fromhex(golden["secret_be"])
+    got = eng.srs_read(0, 64)
+    want = oracle.srs_g1(64, secret)
+    for i in range(64):
+        assert oracle.p1_compress(got[i]) == oracle.p1_compress(want[i]), i
+    for k in (100, 1024):
+        assert oracle.p1_compress(eng.srs_read(k, 1)[0]).hex() == golden["srs_g1"][str(k)]
+    assert K.G1Point(got[0]).compress().hex() == golden["constants"]["compress_G"]
+
+
+def test_srs_load_strided_jacobian(oracle, golden):
+    """kzg_srs_load_g1 takes &srs[0].g1 with stride size_of::<SetupArtifact>() = 432 and points with
+    arbitrary Z (reference src/trusted_setup.rs:31-35, 54-62)."""
+    secret = bytes.fromhex(golden["secret_be"])
+    n = 300
+    srs = oracle.srs_g1(n, secret)
+    art = np.zeros((n, 54), dtype=np.uint64)  # 432 bytes per artifact: g1 then a dummy g2 area
+    rnd = random.Random(1)
+    for i in range(n):
+        lam = np.array([rnd.randrange(1, 1 << 60) for _ in range(6)], dtype=np.uint64)
+        lam[5] &= np.uint64(0x0FFFFFFFFFFFFFFF)
+        tmp = oracle.p1_zeros(1)
+        oracle.lib().oracle_p1_rescale(tmp.ctypes.data, srs[i].ctypes.data, lam.ctypes.data)
+        art[i, :18] = tmp[0]
+        art[i, 18:] = 0xABCDEF
+    eng = K.Engine(0)
+    try:
+        eng.srs_load(art)  # stride = 432 from the array
+        back = eng.srs_read(0, n)
+        for i in range(n):
+            assert oracle.p1_compress(back[i]) == oracle.p1_compress(srs[i]), i
+        c = oracle.bench_coefficients(n)
+        rc, want = oracle.commit_naive(c, srs)
+        assert rc == 0
+        assert eng.commit_limbs(c).compress() == oracle.p1_compress(want)
+    finally:
+        eng.close()
+
+
+# ---------------------------------------------------------------- commit / open on the bench inputs
+
+@pytest.mark.parametrize("degree", [1, 2, 3, 100, 500, 1000, 1024, 2500])
+def test_commit_and_proof_bench_degrees(engines, oracle, golden, degree):
+    eng = engines.bench_srs(SMALL_N)
+    c, z, y = _bench_poly(oracle, degree)
+    case = _case(golden, degree)
+    assert "%x" % y.v == case["y"]
+    poly = K.Polynomial.from_limbs(c)
+    assert poly.commit(eng).compress().hex() == case["commit"]
+    assert K.Evaluation(z, y).generate_proof(poly, eng).compress().hex() == case["proof"]
+    assert poly.evaluate(z, eng).result == y
+
+
+def test_commit_against_oracle_naive_loop(engines, oracle, golden):
+    secret = bytes.fromhex(golden["secret_be"])
+    eng = engines.bench_srs(SMALL_N)
+    srs = oracle.srs_g1(400, secret)
+    rnd = random.Random(21)
+    for n in (1, 2, 7, 64, 65, 255, 400):
+        c = oracle.fr_from_ints([rnd.randrange(K.R_MODULUS) for _ in range(n)])
+        rc, want = oracle.commit_naive(c, srs[:n])
+        assert rc == 0
+        assert eng.commit_limbs(c).compress() == oracle.p1_compress(want), n
+
+
+def test_kate_proof_random_i128_like_reference_lib_tests(engines, oracle, golden):
+    """Shape of src/lib.rs:51-94: random i128 coefficients and points (about half negative, i.e.
+    full-width scalars r - |a|), degrees 1, 2 and random below 2000."""
+    secret = bytes.fromhex(golden["secret_be"])
+    eng = engines.bench_srs(SMALL_N)
+    srs = oracle.srs_g1(2000, secret)
+    rnd = random.Random(2024)
+    degrees = [1] * 3 + [2] * 3 + [rnd.randrange(1, 2000) for _ in range(4)]
+    for d in degrees:
+        ints = [rnd.randrange(-(1 << 127), 1 << 127) for _ in range(d + 1)]
+        poly = K.Polynomial.try_from(ints)
+        z = K.Scalar.from_i128(rnd.randrange(-(1 << 127), 1 << 127))
+        ev = poly.evaluate(z, eng)
+        c = np.stack([oracle.fr_from_i128(a) for a in ints])[: poly.degree() + 1]
+        assert np.array_equal(c, poly.limbs)
+        zo = oracle.fr_from_i128(int(z.v) if z.v < (1 << 127) else int(z.v) - K.R_MODULUS)
+        assert oracle.fr_to_int(zo) == z.v
+        yo = oracle.poly_evaluate(c, zo)
+        assert oracle.fr_to_int(yo) == ev.result.v
+        rc, cm = oracle.commit_naive(c, srs[: len(c)])
+        assert rc == 0 and poly.commit(eng).compress() == oracle.p1_compress(cm)
+        rc, pf = oracle.generate_proof(c, zo, yo, srs[: len(c)])
+        assert rc == 0 and ev.generate_proof(poly, eng).compress() == oracle.p1_compress(pf)
+
+
+def test_commit_le_bytes_entry_point(engines, oracle, golden):
+    eng = engines.bench_srs(SMALL_N)
+    c = oracle.bench_coefficients(1025)
+    le = b"".join(oracle.fr_to_int(r).to_bytes(32, "little") for r in c)
+    assert eng.commit_le_bytes(le).compress().hex() == _case(golden, 1024)["commit"]
+
+
+# ---------------------------------------------------------------- edge cases and errors
+
+def test_edge_cases_from_golden(engines, golden):
+    eng = engines.bench_srs(SMALL_N)
+    for e in golden["edge"]:
+        ints = [int(c, 16) for c in e["coeffs"]]
+        limbs = K.scalars_to_limbs(ints)
+        z, y = K.Scalar(int(e["z"], 16)), K.Scalar(int(e["y"], 16))
+        assert eng.commit_limbs(limbs).compress().hex() == e["commit"], e["name"]
+        if e["error"] is None:
+            assert eng.open_limbs(limbs, z, y).compress().hex() == e["proof"], e["name"]
+        else:
+            with pytest.raises(K.KzgError) as ei:
+                eng.open_limbs(limbs, z, y)
+            assert str(ei.value) == e["error"], e["name"]
+
+
+def test_degree_too_high(engines, oracle):
+    eng = engines.bench_srs(SMALL_N)
+    c = oracle.bench_coefficients(SMALL_N + 5)
+    with pytest.raises(K.KzgError) as ei:
+        eng.commit_limbs(c)
+    assert ei.value.status == K.KZG_ERR_DEGREE_TOO_HIGH
+    assert str(ei.value).startswith("Setup does not allow for commitment generation")
+    # trailing zeros beyond the SRS are not a degree: the reference truncates at construction
+    padded = np.concatenate([oracle.bench_coefficients(10), np.zeros((SMALL_N, 4), dtype=np.uint64)])
+    assert eng.commit_limbs(padded).compress() == eng.commit_limbs(padded[:10]).compress()
+    # a proof needs one point fewer than the commitment (quotient has degree d - 1)
+    c2 = oracle.bench_coefficients(SMALL_N + 1)
+    z = K.Scalar(12345)
+    y = K.Scalar.from_limbs(oracle.poly_evaluate(c2, oracle.fr_from_int(12345)))
+    rc, q = oracle.quotient(c2, oracle.fr_from_int(12345), oracle.fr_from_int(y.v))
+    assert rc == 0
+    assert eng.open_limbs(c2, z, y).compress() == eng.commit_limbs(q).compress()
+    c3 = oracle.bench_coefficients(SMALL_N + 2)
+    y3 = K.Scalar.from_limbs(oracle.poly_evaluate(c3, oracle.fr_from_int(12345)))
+    with pytest.raises(K.KzgError) as ei:
+        eng.open_limbs(c3, z, y3)
+    assert ei.value.status == K.KZG_ERR_DEGREE_TOO_HIGH
+
+
+def test_commit_before_srs_is_an_error():
+    eng = K.Engine(0)
+    try:
+        with pytest.raises(K.KzgError) as ei:
+            eng.commit_limbs(np.zeros((3, 4), dtype=np.uint64))
+        assert ei.value.status == K.KZG_ERR_NO_SRS
+    finally:
+        eng.close()
+
+
+# ---------------------------------------------------------------- quotient / evaluate element-wise
+
+@pytest.mark.parametrize("n", [2, 3, 9, 255, 2048, 2049, 4097, 70001])
+def test_quotient_elementwise(oracle, n):
+    rnd = random.Random(n)
+    eng = K.Engine(0)
+    try:
+        ci = [rnd.randrange(K.R_MODULUS) for _ in range(n)]
+        c = K.scalars_to_limbs(ci)
+        z = K.Scalar(rnd.randrange(K.R_MODULUS))
+        y = eng.evaluate_limbs(c, z)
+        yo = oracle.poly_evaluate(c, oracle.fr_from_int(z.v))
+        assert oracle.fr_to_int(yo) == y.v
+        rc, q_want = oracle.quotient(c, oracle.fr_from_int(z.v), yo)
+        assert rc == 0
+        q_got = eng.quotient_limbs(c, z, y)
+        assert np.array_equal(q_got, q_want)
+        with pytest.raises(K.KzgError) as ei:
+            eng.quotient_limbs(c, z, K.Scalar(y.v + 1))
+        assert ei.value.status == K.KZG_ERR_REMAINDER
+    finally:
+        eng.close()
+
+
+# ---------------------------------------------------------------- adversarial trusted setups
+
+@pytest.mark.parametrize("secret_int,label", [(1, "all points equal G"), (0, "points at infinity"),
+                                              (K.R_MODULUS - 1, "alternating G, -G")])
+def test_degenerate_secrets_exercise_exceptional_group_law(oracle, secret_int, label):
+    """SRS[i] = [s^i]G with s in {1, 0, -1}: every bucket sees equal points (doubling branch),
+    infinities, or opposite points (cancellation).  Bit-exactness needs the complete group law."""
+    secret = secret_int.to_bytes(32, "big")
+    n = 700
+    eng = K.SetupArtifactsGenerator(secret).take(n)
+    try:
+        srs = oracle.srs_g1(n, secret)
+        back = eng.srs_read(0, n)
+        for i in (0, 1, 2, 3, n - 1):
+            assert oracle.p1_compress(back[i]) == oracle.p1_compress(srs[i]), (label, i)
+        rnd = random.Random(99)
+        for coeffs in ([rnd.randrange(K.R_MODULUS) for _ in range(n)], [12345] * n, [1] * n,
+                       [rnd.randrange(1 << 20) for _ in range(n)]):
+            c = K.scalars_to_limbs(coeffs)
+            rc, want = oracle.commit_pippenger(c, srs, threads=4)
+            assert rc == 0
+            assert eng.commit_limbs(c).compress() == oracle.p1_compress(want), label
+    finally:
+        eng.close()
+
+
+def test_skewed_scalars_heavy_buckets(engines, oracle, golden):
+    """All coefficients equal / tiny / r - small: one bucket per window takes every point."""
+    secret = bytes.fromhex(golden["secret_be"])
+    eng = engines.bench_srs(SMALL_N)
+    srs = oracle.srs_g1(SMALL_N, secret)
+    for coeffs in ([K.R_MODULUS - 1] * SMALL_N, [7] * SMALL_N, [0] * 100 + [3] * (SMALL_N - 100),
+                   [(1 << 254) + 5] * SMALL_N):
+        c = K.scalars_to_limbs(coeffs)
+        rc, want = oracle.commit_pippenger(c, srs, threads=8)
+        assert rc == 0
+        assert eng.commit_limbs(c).compress() == oracle.p1_compress(want)
+
+
+# ---------------------------------------------------------------- 2^16 (BASELINE config 2)
+
+def test_degree_2_16_commit_and_proof(engines, oracle, golden):
+    d = 1 << 16
+    eng = engines.bench_srs(d + 1)
+    c, z, y = _bench_poly(oracle, d)
+    case = _case(golden, d)
+    assert "%x" % y.v == case["y"]
+    got = eng.commit_limbs(c)
+    assert got.compress().hex() == case["commit"]
+    assert eng.open_limbs(c, z, y).compress().hex() == case["proof"]
+    # the SRS itself, spot-checked against the oracle and the fixtures
+    secret = bytes.fromhex(golden["secret_be"])
+    assert oracle.p1_compress(eng.srs_read(65535, 2)[1]).hex() == golden["srs_g1"]["65536"]
+    assert oracle.p1_compress(eng.srs_read(12345, 1)[0]) == oracle.p1_compress(oracle.srs_g1_at(12345, secret))
+    # full-size oracle run of the same MSM (bucket method on the host cores)
+    srs = eng.srs_read(0, d + 1)
+    rc, want = oracle.commit_pippenger(c, srs, threads=8)
+    assert rc == 0 and got.compress() == oracle.p1_compress(want)
+
+
+def test_sharded_commit_equals_unsharded(engines, oracle, golden):
+    """The multi-GPU decomposition with K virtual shards on one device: rank g holds SRS slice
+    [lo, hi) and commits the matching coefficient slice; the sum of partials is the commitment."""
+    from kzg_poly_commit_exploration_amd.sharding import shard_range
+
+    d = 1 << 16
+    n = d + 1
+    secret = bytes.fromhex(golden["secret_be"])
+    c = oracle.bench_coefficients(n)
+    parts = []
+    for rank in range(4):
+        lo, hi = shard_range(n, rank, 4)
+        eng = K.Engine(0)
+        try:
+            eng.srs_generate(secret, hi - lo, first=lo)
+            parts.append(eng.commit_limbs(c[lo:hi]))
+        finally:
+            eng.close()
+    assert K.G1Point.sum(parts).compress().hex() == _case(golden, d)["commit"]
+
+
+def test_linearity_and_determinism(engines, oracle):
+    eng = engines.bench_srs((1 << 16) + 1)
+    rnd = random.Random(17)
+    n = 50000
+    a = [rnd.randrange(K.R_MODULUS) for _ in range(n)]
+    b = [rnd.randrange(K.R_MODULUS) for _ in range(n)]
+    ca, cb = eng.commit_limbs(K.scalars_to_limbs(a)), eng.commit_limbs(K.scalars_to_limbs(b))
+    cab = eng.commit_limbs(K.scalars_to_limbs([x + y for x, y in zip(a, b)]))
+    assert K.G1Point.sum([ca, cb]) == cab
+    assert eng.commit_limbs(K.scalars_to_limbs(a)).compress() == ca.compress()  # atomics order is irrelevant
+
+
+def test_pipelined_slots_device_resident(engines, oracle, golden):
+    d = 1 << 16
+    eng = engines.bench_srs(d + 1)
+    c, z, y = _bench_poly(oracle, d)
+    case = _case(golden, d)
+    dptr = eng.dev_alloc(c.nbytes)
+    try:
+        eng.dev_upload(dptr, c)
+        slots = eng.num_slots()
+        for s in range(slots):
+            if s % 2 == 0:
+                eng.commit_submit(s, dptr, d + 1)
+            else:
+                eng.open_submit(s, dptr, d + 1, z, y)
+        with pytest.raises(K.KzgError) as ei:
+            eng.commit_submit(0, dptr, d + 1)
+        assert ei.value.status == K.KZG_ERR_BUSY
+        for s in range(slots):
+            got = eng.wait(s).compress().hex()
+            assert got == (case["commit"] if s % 2 == 0 else case["proof"])
+    finally:
+        eng.dev_free(dptr)
+
+
+# ---------------------------------------------------------------- 2^20 (BASELINE config 3, the bench workload)
+
+def test_degree_2_20_commit_and_proof_golden(engines, oracle, golden):
+    d = 1 << 20
+    eng = engines.bench_srs(d + 1)
+    secret = bytes.fromhex(golden["secret_be"])
+    assert oracle.p1_compress(eng.srs_read(d, 1)[0]).hex() == golden["srs_g1"][str(d)]
+    k = 777777
+    assert oracle.p1_compress(eng.srs_read(k, 1)[0]) == oracle.p1_compress(oracle.srs_g1_at(k, secret))
+    c, z, y = _bench_poly(oracle, d)
+    case = _case(golden, d)
+    assert "%x" % y.v == case["y"]
+    assert eng.evaluate_limbs(c, z) == y
+    assert eng.commit_limbs(c).compress().hex() == case["commit"]
+    assert eng.open_limbs(c, z, y).compress().hex() == case["proof"]
+    # size-independent property at full size: commit(P) = commit(P_low) + commit(P_high)
+    half = (d + 1) // 2
+    lo = c.copy()
+    lo[half:] = 0
+    hi = c.copy()
+    hi[:half] = 0
+    assert K.G1Point.sum([eng.commit_limbs(lo), eng.commit_limbs(hi)]).compress().hex() == case["commit"]
+    # quotient * (x - z) + y = P, checked by committing: [Q(s)](s - z) + y = P(s) is what the verifier
+    # pairs; here: element-wise against the oracle on a window of the quotient
+    q = eng.quotient_limbs(c, z, y)
+    rc, q_want = oracle.quotient(c, oracle.fr_from_int(z.v), oracle.fr_from_int(y.v))
+    assert rc == 0 and np.array_equal(q, q_want)

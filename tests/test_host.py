@@ -1,0 +1,53 @@
+"""CPU: host-side mirror of the reference's value types (no device work)."""
+import random
+
+import numpy as np
+
+import kzg_poly_commit_exploration_amd as K
+
+
+def test_i128_to_scalar_using_le():
+    # reference src/scalar.rs:350-368
+    rnd = random.Random(3)
+    for _ in range(100):
+        a = rnd.randrange(-(1 << 127), 1 << 127)
+        s = K.Scalar.from_i128(a)
+        expect = a if a > 0 else K.R_MODULUS - (-a)
+        assert s.to_le_bytes() == (expect % K.R_MODULUS).to_bytes(32, "little")
+    assert K.Scalar.from_i128(0).is_zero()
+
+
+def test_u128_byte_orders():
+    # reference src/scalar.rs:370-389
+    rnd = random.Random(4)
+    for _ in range(20):
+        a = rnd.randrange(1 << 128)
+        le = a.to_bytes(32, "little")
+        assert K.Scalar.from_le_bytes(le).to_le_bytes() == le
+        assert K.Scalar.from_be_bytes(le[::-1]).to_be_bytes() == le[::-1]
+
+
+def test_display_and_pow():
+    # reference src/scalar.rs:391-414
+    assert str(K.Scalar.from_i128(123456789)) == "123456789"
+    for n in range(10):
+        assert K.Scalar.from_i128(999983).pow(n).v == pow(999983, n, K.R_MODULUS)
+
+
+def test_limbs_match_oracle_layout(oracle):
+    for v in (0, 1, 5, K.R_MODULUS - 1, 1 << 200):
+        assert [int(x) for x in K.Scalar(v).limbs()] == [int(x) for x in oracle.fr_from_int(v)]
+        assert K.Scalar.from_limbs(oracle.fr_from_int(v)).v == v % K.R_MODULUS
+    arr = K.scalars_to_limbs([3, -4, K.R_MODULUS + 9])
+    assert K.limbs_to_scalars(arr) == [3, K.R_MODULUS - 4, 9]
+
+
+def test_create_polynomial_with_tailing_zeros():
+    # reference src/polynomial.rs:301-321
+    assert K.Polynomial.try_from([0, 0, 0, 0, 0]).degree() == 0
+    assert K.Polynomial.try_from([1, 0, 0, 0, 0]).degree() == 0
+    assert K.Polynomial.try_from([1, 0, 1, 0, 0]).degree() == 2
+    assert K.Polynomial.try_from([1, 0, 1, 0, 0, 5]).degree() == 5
+    assert K.Polynomial.try_from([]).degree() == 0
+    p = K.Polynomial.from_limbs(K.scalars_to_limbs([1, 0, 1, 0, 0]))
+    assert p.degree() == 2 and [c.v for c in p.coefficients()] == [1, 0, 1]

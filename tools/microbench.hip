@@ -194,7 +194,8 @@ __global__ void __launch_bounds__(256) k_madd(u32* io, int iters) {
     XYZZ acc = XYZZ::inf();
     Affine q = p;
     xyzz_madd(acc, p, false);
-    xyzz_madd(acc, p, false);  // acc = 2P (exercises the rare doubling path) so that acc != +-P below
+    xyzz_madd(acc, p, false);  // acc = 2P (exercises the rare doubling path)
+    acc = xyzz_dbl(acc);       // 4P: the loop below walks 4P <-> 3P/5P and never meets +-P
     for (int it = 0; it < iters; it++) {
         xyzz_madd(acc, q, (it + tid) & 1);
     }
@@ -206,6 +207,25 @@ __global__ void __launch_bounds__(256) k_madd(u32* io, int iters) {
             io[48 + i] = acc.ZZ.l[i];
             io[60 + i] = acc.ZZZ.l[i];
         }
+    }
+    if (acc.X.l[3] == 0x12345 && acc.Y.l[2] == 77) io[80] = 1;
+}
+
+__global__ void __launch_bounds__(256) k_add(u32* io, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Affine p;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        p.x.l[i] = io[i];
+        p.y.l[i] = io[12 + i];
+    }
+    XYZZ acc = xyzz_from_affine(p);
+    acc = xyzz_dbl(acc);
+    XYZZ run = xyzz_dbl(acc);
+    xyzz_madd(run, p, tid & 1);
+    for (int it = 0; it < iters; it++) {
+        xyzz_add(run, acc);
+        xyzz_add(acc, run);
     }
     if (acc.X.l[3] == 0x12345 && acc.Y.l[2] == 77) io[80] = 1;
 }
@@ -270,7 +290,7 @@ int main() {
                         0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
     u32* dio;
     CHECK(hipMalloc(&dio, sizeof h));
-    for (int wps = 1; wps <= 4; wps *= 2) {
+    for (int wps = 1; wps <= 4; wps++) {
         int grid = cus * wps;
         const int fit = 200;
         memcpy(h, GX, 48);
@@ -286,6 +306,8 @@ int main() {
         ms = time_kernel(k_madd, grid, block, 3, dio, mit);
         double nadd = (double)grid * block * mit;
         printf("{\"bench\": \"xyzz_madd\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gadd_s\": %.3f}\n", wps, ms, nadd / ms / 1e6);
+        ms = time_kernel(k_add, grid, block, 3, dio, mit / 2);
+        printf("{\"bench\": \"xyzz_add\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gadd_s\": %.3f}\n", wps, ms, nadd / ms / 1e6);
     }
     // correctness probes (checked offline against Python big ints): 3 iterations of the fpmul loop
     memcpy(h, GX, 48);
