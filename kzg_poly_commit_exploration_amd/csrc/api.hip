@@ -50,6 +50,8 @@ struct Slot {
     uint32_t *d_hist = nullptr, *d_offs = nullptr, *d_block_sums = nullptr;
     uint32_t *d_rank = nullptr, *d_sorted = nullptr;
     void* d_buckets = nullptr;
+    void *d_part_a = nullptr, *d_part_b = nullptr;  // head / tail partials of the accumulation segments
+    uint32_t* d_heavy_list = nullptr;
     void* d_arena = nullptr;     // acc[] / run[] of every level
     void* d_sumtmp[2] = {nullptr, nullptr};
     void* d_final = nullptr;
@@ -60,7 +62,7 @@ struct Slot {
     uint32_t* d_q = nullptr;      // quotient
     uint32_t* d_chunk = nullptr;
     uint32_t* d_block = nullptr;
-    uint32_t* d_small = nullptr;  // [0..1] flags, [8..15] P(z), [16..23] c0, [24] tail flag
+    uint32_t* d_small = nullptr;  // [0..1] flags, [8..15] P(z), [16..23] c0, [24] tail flag, [25] heavy count
     uint32_t* h_small = nullptr;  // pinned mirror
     // state of the job in flight
     SlotKind kind = SLOT_IDLE;
@@ -102,10 +104,11 @@ namespace {
 
 void free_slot_msm(Slot& s) {
     hipFree(s.d_hist); hipFree(s.d_offs); hipFree(s.d_block_sums); hipFree(s.d_rank); hipFree(s.d_sorted);
-    hipFree(s.d_buckets); hipFree(s.d_arena); hipFree(s.d_sumtmp[0]); hipFree(s.d_sumtmp[1]); hipFree(s.d_final);
+    hipFree(s.d_buckets); hipFree(s.d_part_a); hipFree(s.d_part_b); hipFree(s.d_heavy_list); hipFree(s.d_arena); hipFree(s.d_sumtmp[0]); hipFree(s.d_sumtmp[1]); hipFree(s.d_final);
     if (s.h_final) hipHostFree(s.h_final);
     s.d_hist = s.d_offs = s.d_block_sums = s.d_rank = s.d_sorted = nullptr;
-    s.d_buckets = s.d_arena = s.d_sumtmp[0] = s.d_sumtmp[1] = s.d_final = nullptr;
+    s.d_buckets = s.d_part_a = s.d_part_b = s.d_arena = s.d_sumtmp[0] = s.d_sumtmp[1] = s.d_final = nullptr;
+    s.d_heavy_list = nullptr;
     s.h_final = nullptr;
 }
 void free_slot_poly(Slot& s) {
@@ -180,6 +183,9 @@ int setup_slots(kzg_ctx* ctx) {
         HIP_TRY(ctx, hipMalloc(&s.d_rank, (pairs ? pairs : 1) * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_sorted, (pairs ? pairs : 1) * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_buckets, (size_t)cfg.nb * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_part_a, (size_t)kMaxAccumLanes * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_part_b, (size_t)kMaxAccumLanes * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_heavy_list, (size_t)cfg.nb * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_arena, ctx->arena_records * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_sumtmp[0], ctx->sumtmp_records * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_sumtmp[1], ctx->sumtmp_records * kXyzzBytes));
@@ -238,9 +244,16 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
     launch_bucket_scan(st, s.d_hist, cfg.nb, s.d_offs, s.d_block_sums);
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 2], st));
     launch_scatter(st, d_scalars, is_mont, (uint32_t)n, (uint32_t)ctx->n, cfg, s.d_offs, s.d_rank, s.d_sorted);
+    const uint64_t max_refs = (uint64_t)n * cfg.W;
+    const uint32_t L = accumulate_segment_len(max_refs);
+    HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)cfg.nb * kXyzzBytes, st));  // zero = infinity
+    HIP_TRY(ctx, hipMemsetAsync(s.d_small + 25, 0, 4, st));
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 3], st));
-    launch_bucket_accumulate(st, ctx->d_table, s.d_sorted, s.d_offs, nullptr, cfg.nb, s.d_buckets);
+    launch_bucket_accumulate(st, ctx->d_table, s.d_sorted, s.d_offs, cfg.nb, L, max_refs, s.d_buckets, s.d_part_a,
+                             s.d_part_b);
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], st));
+    launch_bucket_finalize(st, s.d_offs, cfg.nb, L, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_list,
+                           s.d_small + 25);
     // reduction levels
     const char* items = (const char*)s.d_buckets;
     for (size_t li = 0; li < ctx->levels.size(); li++) {

@@ -31,16 +31,20 @@ void launch_digits_hist(hipStream_t s, const uint32_t* d_scalars, int scalars_ar
 // exclusive prefix sum of the bucket histogram -> d_offs[0..nb] (d_offs[nb] = number of pairs)
 void launch_bucket_scan(hipStream_t s, const uint32_t* d_hist, uint32_t nb, uint32_t* d_offs,
                         uint32_t* d_block_sums);
-// orders buckets by decreasing population so that the lanes of a wavefront run equally long
-void launch_bucket_order(hipStream_t s, const uint32_t* d_hist, uint32_t nb, uint32_t* d_count_hist,
-                         uint32_t* d_order);
 // pass 2: counting-sort scatter of (table index | sign << 31) into bucket-major order
 void launch_scatter(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n,
                     uint32_t table_stride, MsmConfig cfg, const uint32_t* d_offs, const uint32_t* d_rank,
                     uint32_t* d_sorted);
-// bucket accumulation (dominant kernel): one lane per bucket, XYZZ += affine table point
-void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted,
-                              const uint32_t* d_offs, const uint32_t* d_order, uint32_t nb, void* d_buckets);
+// bucket accumulation (dominant kernel): one lane per segment of L sorted references
+constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on ceil(max_refs / accumulate_segment_len(max_refs))
+uint32_t accumulate_segment_len(uint64_t max_refs);
+void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
+                              uint32_t nb, uint32_t L, uint64_t max_refs, void* d_buckets /* pre-zeroed */,
+                              void* d_part_a, void* d_part_b);
+// adds the head / tail partials of buckets that span several segments (serial, or tree for long spans)
+void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t L, const void* d_part_a,
+                            const void* d_part_b, void* d_buckets, uint32_t* d_heavy_list,
+                            uint32_t* d_heavy_count /* pre-zeroed */);
 // one level of the weighted running-sum reduction over `n_items` XYZZ items in chunks of m:
 //   acc[k] = sum_{t<m} (t+1) * in[k*m + t],   run[k] = sum_{t<m} in[k*m + t]
 void launch_wsum_level(hipStream_t s, const void* d_in, uint32_t n_items, uint32_t m, void* d_acc, void* d_run);

@@ -1,24 +1,26 @@
 // msm_accum.hip -- bucket accumulation, the dominant kernel of the commitment.
 //
 // Replaces the reference's hot loop  commitment.add(srs[i].g1.mult(c_i))  (src/polynomial.rs:208-212):
-// after msm_sort every bucket owns a contiguous list of signed references into the window table
-// T[j*n+i] = 2^(c*j) SRS[i]; one lane adds its bucket's points into an XYZZ accumulator held in
-// VGPRs (8M + 2S per point, 384-bit Montgomery arithmetic on v_mad_u64_u32).
+// after msm_sort the (point, sign) references are sorted by bucket; their concatenation is cut into
+// equal segments of L references and ONE LANE OWNS ONE SEGMENT, whatever buckets it crosses.  Every
+// lane therefore performs the same number of mixed additions (XYZZ accumulator in VGPRs += affine
+// table point, 8M + 2S of 384-bit Montgomery arithmetic on v_mad_u64_u32), and wavefronts stay
+// converged for any scalar distribution -- uniform, the reference's i128-derived inputs, or all
+// coefficients equal.  A lane closes a bucket it covers completely by storing it; the (at most two)
+// buckets it shares with its neighbours leave a head / tail partial that k_bucket_finalize adds up.
 //
-// Roofline: VALU (integer multiply) bound.  Per point ~2900 v_mad_u64_u32 + ~6000 other VALU ops
-// against 96 B fetched from the table + 4 B of reference.  Algorithmic HBM bytes per commitment are
+// Roofline: VALU (integer multiply) bound.  Per reference ~2900 v_mad_u64_u32 + ~6000 other VALU ops
+// against 96 B gathered from the table + 4 B of reference.  Algorithmic HBM bytes per commitment are
 // those of SURVEY.md section 8(d): 128 B x n + 144 B.
-//
-// Load balance: bucket populations are Poisson-like, so a workgroup first orders its 256 buckets by
-// population in LDS (counting sort on LDS atomics); each wavefront then owns 64 buckets of nearly
-// equal length and its lanes stay converged.
 #include "engine.h"
 #include "g1.hip.h"
 
 namespace kzg {
 
 constexpr int kAccumBlock = 256;
-constexpr int kCountBins = 1024;
+constexpr uint32_t kSerialSpan = 48;  // buckets spanning more segments than this go to the tree kernel
+constexpr int kHeavyBlock = 256;
+constexpr int kHeavyGrid = 512;
 
 KZG_DEV Affine load_affine(const uint4* __restrict__ table, uint32_t idx) {
     const uint4* p = table + (size_t)idx * 6;
@@ -48,77 +50,179 @@ KZG_DEV void store_xyzz(uint4* __restrict__ out, const XYZZ& a) {
         }
     }
 }
+KZG_DEV XYZZ load_xyzz(const uint4* __restrict__ in) {
+    XYZZ a;
+    Fp* f[4] = {&a.X, &a.Y, &a.ZZ, &a.ZZZ};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            uint4 v = in[q * 3 + t];
+            f[q]->l[4 * t] = v.x;
+            f[q]->l[4 * t + 1] = v.y;
+            f[q]->l[4 * t + 2] = v.z;
+            f[q]->l[4 * t + 3] = v.w;
+        }
+    }
+    return a;
+}
 
+// largest b in [0, nb) with offs[b] <= pos  (offs is non-decreasing, offs[0] = 0)
+KZG_DEV uint32_t bucket_of(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t pos) {
+    uint32_t lo = 0, hi = nb;  // invariant: offs[lo] <= pos, (hi == nb or offs[hi] > pos)
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (offs[mid] <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// One lane per segment [lane*L, lane*L + L) of the sorted references.
+//   complete runs   -> buckets[b]
+//   run touching the segment start (bucket continues from the previous lane, or the whole segment
+//   lies inside one bucket) -> part_a[lane];  run touching only the segment end -> part_b[lane]
 __global__ void __launch_bounds__(kAccumBlock) k_bucket_accumulate(const uint4* __restrict__ table,
                                                                   const uint32_t* __restrict__ sorted,
                                                                   const uint32_t* __restrict__ offs, uint32_t nb,
-                                                                  uint4* __restrict__ buckets) {
-    __shared__ u32 s_hist[kCountBins];
-    __shared__ u32 s_order[kAccumBlock];
-    const int t = threadIdx.x;
-    const uint32_t b0 = blockIdx.x * kAccumBlock;
+                                                                  uint32_t L, uint4* __restrict__ buckets,
+                                                                  uint4* __restrict__ part_a,
+                                                                  uint4* __restrict__ part_b) {
+    const uint32_t lane = blockIdx.x * kAccumBlock + threadIdx.x;
+    const uint32_t M = offs[nb];
+    const uint64_t start64 = (uint64_t)lane * L;
+    if (start64 >= M) return;
+    const uint32_t start = (uint32_t)start64;
+    const uint32_t end = (M - start < L) ? M : start + L;
 
-    // ---- order this workgroup's buckets by decreasing population ----
-    for (int q = t; q < kCountBins; q += kAccumBlock) s_hist[q] = 0;
-    __syncthreads();
-    uint32_t my_b = b0 + t;
-    u32 beg = 0, cnt = 0;
-    if (my_b < nb) {
-        beg = offs[my_b];
-        cnt = offs[my_b + 1] - beg;
-    }
-    u32 key = cnt < (u32)kCountBins - 1 ? cnt : (u32)kCountBins - 1;
-    key = (kCountBins - 1) - key;  // descending
-    u32 myrank = atomicAdd(&s_hist[key], 1u);
-    __syncthreads();
-    // exclusive scan of 1024 bins by 256 threads (4 bins each + block scan)
-    {
-        u32 v0 = s_hist[4 * t], v1 = s_hist[4 * t + 1], v2 = s_hist[4 * t + 2], v3 = s_hist[4 * t + 3];
-        u32 sum = v0 + v1 + v2 + v3;
-        __shared__ u32 s_scan[kAccumBlock];
-        s_scan[t] = sum;
-        __syncthreads();
-        for (int off = 1; off < kAccumBlock; off <<= 1) {
-            u32 add = t >= off ? s_scan[t - off] : 0u;
-            __syncthreads();
-            s_scan[t] += add;
-            __syncthreads();
-        }
-        u32 ex = s_scan[t] - sum;
-        s_hist[4 * t] = ex;
-        s_hist[4 * t + 1] = ex + v0;
-        s_hist[4 * t + 2] = ex + v0 + v1;
-        s_hist[4 * t + 3] = ex + v0 + v1 + v2;
-        __syncthreads();
-    }
-    s_order[s_hist[key] + myrank] = (u32)t;
-    __syncthreads();
-    const int src = (int)s_order[t];  // lane t takes over the bucket first seen by lane `src`
-    // fetch (beg, cnt) of the adopted bucket
-    __shared__ u32 s_beg[kAccumBlock], s_cnt[kAccumBlock];
-    s_beg[t] = beg;
-    s_cnt[t] = cnt;
-    __syncthreads();
-    beg = s_beg[src];
-    cnt = s_cnt[src];
-    const uint32_t b = b0 + (uint32_t)src;
-    if (b >= nb) return;
-
-    // ---- accumulate ----
+    uint32_t b = bucket_of(offs, nb, start);
+    uint32_t b_beg = offs[b], b_end = offs[b + 1];
+    uint32_t run_start = start;
     XYZZ acc = XYZZ::inf();
-    for (u32 e = 0; e < cnt; e++) {
-        u32 ref = sorted[beg + e];
+    for (uint32_t e = start; e < end; e++) {
+        if (e == b_end) {
+            // bucket b ends here: flush its run and move to the bucket that owns e (skipping empties)
+            uint4* dst = (run_start == b_beg) ? buckets + (size_t)b * 12 : part_a + (size_t)lane * 12;
+            store_xyzz(dst, acc);  // a run that began inside the bucket necessarily began at `start`
+            acc = XYZZ::inf();
+            do {
+                b++;
+                b_beg = b_end;
+                b_end = offs[b + 1];
+            } while (b_end <= e);
+            run_start = e;
+        }
+        u32 ref = sorted[e];
         Affine p = load_affine(table, ref & 0x7fffffffu);
         xyzz_madd(acc, p, (ref >> 31) != 0);
+    }
+    // last run: [run_start, end)
+    uint4* dst;
+    if (run_start == b_beg && end == b_end) dst = buckets + (size_t)b * 12;  // complete
+    else if (run_start == start) dst = part_a + (size_t)lane * 12;            // covers the whole segment
+    else dst = part_b + (size_t)lane * 12;                                    // tail shared with the next lane
+    store_xyzz(dst, acc);
+}
+
+// Buckets that span several segments: add up their partials (first segment's tail or whole, whole
+// middle segments, last segment's head).  One lane per bucket; very long spans (skewed scalars) are
+// queued for k_bucket_heavy.
+__global__ void __launch_bounds__(64) k_bucket_finalize(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t L,
+                                                        const uint4* __restrict__ part_a,
+                                                        const uint4* __restrict__ part_b,
+                                                        uint4* __restrict__ buckets,
+                                                        uint32_t* __restrict__ heavy_list,
+                                                        uint32_t* __restrict__ heavy_count) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t s = offs[b], e = offs[b + 1];
+    if (s == e) return;  // empty bucket: stays at infinity (buffer pre-zeroed)
+    uint32_t l_lo = s / L, l_hi = (e - 1) / L;
+    if (l_lo == l_hi) return;  // inside one segment: written complete by k_bucket_accumulate
+    if (l_hi - l_lo + 1 > kSerialSpan) {
+        uint32_t slot = atomicAdd(heavy_count, 1u);
+        heavy_list[slot] = b;
+        return;
+    }
+    const uint4* first = (s == l_lo * L) ? part_a + (size_t)l_lo * 12 : part_b + (size_t)l_lo * 12;
+    XYZZ acc = load_xyzz(first);
+    for (uint32_t l = l_lo + 1; l <= l_hi; l++) {
+        XYZZ p = load_xyzz(part_a + (size_t)l * 12);
+        xyzz_add(acc, p);
     }
     store_xyzz(buckets + (size_t)b * 12, acc);
 }
 
+// One workgroup per queued bucket: strided partial sums, then a tree in LDS.
+__global__ void __launch_bounds__(kHeavyBlock) k_bucket_heavy(const uint32_t* __restrict__ offs, uint32_t L,
+                                                              const uint4* __restrict__ part_a,
+                                                              const uint4* __restrict__ part_b,
+                                                              uint4* __restrict__ buckets,
+                                                              const uint32_t* __restrict__ heavy_list,
+                                                              const uint32_t* __restrict__ heavy_count) {
+    __shared__ u32 lds[48 * kHeavyBlock];
+    const int t = threadIdx.x;
+    const uint32_t count = *heavy_count;
+    for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
+        uint32_t b = heavy_list[h];
+        uint32_t s = offs[b], e = offs[b + 1];
+        uint32_t l_lo = s / L, l_hi = (e - 1) / L;
+        XYZZ acc = XYZZ::inf();
+        for (uint32_t l = l_lo + t; l <= l_hi; l += kHeavyBlock) {
+            const uint4* src = (l == l_lo && s != l_lo * L) ? part_b + (size_t)l * 12 : part_a + (size_t)l * 12;
+            XYZZ p = load_xyzz(src);
+            xyzz_add(acc, p);
+        }
+        for (int off = kHeavyBlock / 2; off >= 1; off >>= 1) {
+            __syncthreads();
+            if (t >= off && t < 2 * off) {
+                const Fp* f[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int i = 0; i < 12; i++) lds[(q * 12 + i) * kHeavyBlock + (t - off)] = f[q]->l[i];
+            }
+            __syncthreads();
+            if (t < off) {
+                XYZZ o;
+                Fp* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int i = 0; i < 12; i++) f[q]->l[i] = lds[(q * 12 + i) * kHeavyBlock + t];
+                xyzz_add(acc, o);
+            }
+        }
+        if (t == 0) store_xyzz(buckets + (size_t)b * 12, acc);
+        __syncthreads();
+    }
+}
+
+uint32_t accumulate_segment_len(uint64_t max_refs) {
+    // about one segment per resident lane of the chip (256 CUs x 4 SIMDs x 4 waves x 64 lanes)
+    uint64_t L = (max_refs + 262143) / 262144;
+    if (L < 8) L = 8;
+    return (uint32_t)L;
+}
+
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
-                              const uint32_t*, uint32_t nb, void* d_buckets) {
-    hipLaunchKernelGGL(k_bucket_accumulate, dim3((nb + kAccumBlock - 1) / kAccumBlock), dim3(kAccumBlock), 0, s,
-                       reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb,
-                       reinterpret_cast<uint4*>(d_buckets));
+                              uint32_t nb, uint32_t L, uint64_t max_refs, void* d_buckets, void* d_part_a,
+                              void* d_part_b) {
+    uint32_t lanes = (uint32_t)((max_refs + L - 1) / L);
+    if (!lanes) return;
+    hipLaunchKernelGGL(k_bucket_accumulate, dim3((lanes + kAccumBlock - 1) / kAccumBlock), dim3(kAccumBlock), 0, s,
+                       reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb, L,
+                       reinterpret_cast<uint4*>(d_buckets), reinterpret_cast<uint4*>(d_part_a),
+                       reinterpret_cast<uint4*>(d_part_b));
+}
+
+void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t L, const void* d_part_a,
+                            const void* d_part_b, void* d_buckets, uint32_t* d_heavy_list, uint32_t* d_heavy_count) {
+    hipLaunchKernelGGL(k_bucket_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, d_offs, nb, L,
+                       reinterpret_cast<const uint4*>(d_part_a), reinterpret_cast<const uint4*>(d_part_b),
+                       reinterpret_cast<uint4*>(d_buckets), d_heavy_list, d_heavy_count);
+    hipLaunchKernelGGL(k_bucket_heavy, dim3(kHeavyGrid), dim3(kHeavyBlock), 0, s, d_offs, L,
+                       reinterpret_cast<const uint4*>(d_part_a), reinterpret_cast<const uint4*>(d_part_b),
+                       reinterpret_cast<uint4*>(d_buckets), d_heavy_list, d_heavy_count);
 }
 
 }  // namespace kzg

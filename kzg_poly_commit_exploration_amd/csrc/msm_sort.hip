@@ -12,22 +12,32 @@
 namespace kzg {
 
 MsmConfig choose_msm_config(size_t n) {
-    // c ~ log2(n) - 1: about one resident lane per bucket at 2^20 points and ~50-100 additions per
-    // bucket, while the 2^(c-1)-bucket reduction stays a few percent of the additions.
-    uint32_t lg = 0;
-    while (((size_t)1 << (lg + 1)) <= n) lg++;
-    int c = (int)lg - 1;
-    if (c < 8) c = 8;
-    if (c > 20) c = 20;
+    // Scalars are first folded to |k| <= (r-1)/2 < 2^254 (sign moved onto the point), so
+    // W = ceil(255 / c) signed windows never carry out of the top.  c minimises
+    //     n * W  (mixed additions)  +  8 * 2^(c-1)  (bucket finalisation + reduction, weighted for
+    // the latency of the reduction levels): 17 bits / 15 windows / 65536 buckets at 2^20 points.
+    uint32_t best_c = 8;
+    double best = 1e300;
+    for (uint32_t c = 8; c <= 20; c++) {
+        uint32_t W = (255 + c - 1) / c;
+        double cost = (double)n * W + 8.0 * (double)(1u << (c - 1));
+        if (cost < best) {
+            best = cost;
+            best_c = c;
+        }
+    }
     MsmConfig cfg;
-    cfg.c = (uint32_t)c;
-    cfg.W = (256 + c - 1) / c;
-    cfg.nb = 1u << (c - 1);
+    cfg.c = best_c;
+    cfg.W = (255 + best_c - 1) / best_c;
+    cfg.nb = 1u << (best_c - 1);
     return cfg;
 }
 
-// canonical 256-bit scalar (8 words) from the stored form
-KZG_DEV void load_scalar(const uint32_t* d_scalars, uint32_t i, int is_mont, u32 k[8]) {
+// canonical 256-bit scalar (8 words) from the stored form, folded to the shorter of k and r - k:
+// k * P = (r - k) * (-P).  Returns true when the point has to be negated.  Besides halving the
+// range this makes the reference's "negative" i128 inputs (r - |a|, src/scalar.rs:27-48) as cheap
+// as the positive ones: their upper windows become zero digits, which are skipped.
+KZG_DEV bool load_scalar(const uint32_t* d_scalars, uint32_t i, int is_mont, u32 k[8]) {
     const uint4* p = reinterpret_cast<const uint4*>(d_scalars) + 2 * (size_t)i;
     uint4 lo = p[0], hi = p[1];
     Fr a;
@@ -40,12 +50,23 @@ KZG_DEV void load_scalar(const uint32_t* d_scalars, uint32_t i, int is_mont, u32
         cond_sub_mod(a, 0u);
         cond_sub_mod(a, 0u);
     }
+    // neg = r - a ; use it when neg < a  (a > (r-1)/2)
+    u32 nk[8];
+    u32 br = 0;
 #pragma unroll
-    for (int t = 0; t < 8; t++) k[t] = a.l[t];
+    for (int t = 0; t < 8; t++) nk[t] = subb(FrParams::mod(t), a.l[t], br);
+    // compare nk < a : borrow of nk - a
+    u32 b2 = 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) (void)subb(nk[t], a.l[t], b2);
+    bool flip = b2 != 0;
+#pragma unroll
+    for (int t = 0; t < 8; t++) k[t] = flip ? nk[t] : a.l[t];
+    return flip;
 }
 
 // Signed window recoding, low window first: digit in [-2^(c-1)+1, 2^(c-1)], carry into the next
-// window.  W * c >= 256 > bits(r), so the top window absorbs the last carry.
+// window.  |k| < 2^254 and W * c >= 255, so the top window absorbs the last carry.
 // f(j, magnitude (>0), negative)
 template <class F>
 KZG_DEV void for_each_digit(u32 k[8], uint32_t c, uint32_t W, F&& f) {
@@ -71,7 +92,7 @@ __global__ void __launch_bounds__(256) k_digits_hist(const uint32_t* __restrict_
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 k[8];
-    load_scalar(d_scalars, i, is_mont, k);
+    (void)load_scalar(d_scalars, i, is_mont, k);
     for_each_digit(k, c, W, [&](uint32_t j, u32 mag, bool) {
         u32 r = atomicAdd(&d_hist[mag - 1], 1u);
         d_rank[(size_t)j * n + i] = r;
@@ -85,10 +106,10 @@ __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ d_
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 k[8];
-    load_scalar(d_scalars, i, is_mont, k);
+    const bool flip = load_scalar(d_scalars, i, is_mont, k);
     for_each_digit(k, c, W, [&](uint32_t j, u32 mag, bool neg) {
         u32 pos = d_offs[mag - 1] + d_rank[(size_t)j * n + i];
-        d_sorted[pos] = (j * table_stride + i) | (neg ? 0x80000000u : 0u);
+        d_sorted[pos] = (j * table_stride + i) | ((neg != flip) ? 0x80000000u : 0u);
     });
 }
 
@@ -173,10 +194,6 @@ void launch_bucket_scan(hipStream_t s, const uint32_t* d_hist, uint32_t nb, uint
     hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(kScanBlock), 0, s, d_hist, nb, d_offs, d_block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, d_block_sums, nblocks, d_offs + nb);
     hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(kScanBlock), 0, s, d_offs, nb, d_block_sums);
-}
-
-void launch_bucket_order(hipStream_t, const uint32_t*, uint32_t, uint32_t*, uint32_t*) {
-    // bucket ordering is done per workgroup inside the accumulation kernel (msm_accum.hip)
 }
 
 void launch_scatter(hipStream_t s, const uint32_t* d_scalars, int is_mont, uint32_t n, uint32_t table_stride,
