@@ -7,7 +7,7 @@
 // (accumulator at infinity, equal points, opposite points) are handled explicitly -- they do
 // occur (SRS[0] = G, repeated coefficients) and the output must be bit-exact, not probable.
 #pragma once
-#include "field.hip.h"
+#include "field_fips.hip.h"
 
 namespace kzg {
 
@@ -17,11 +17,11 @@ namespace kzg {
 // calls (one copy of the ~1000-instruction multiplier in the instruction cache instead of ten per
 // addition); otherwise they are inlined.  Chosen per kernel from measurements.
 #ifdef KZG_MUL_CALL
-static __device__ __noinline__ Fp fmul(Fp a, Fp b) { return fe_mul(a, b); }
-static __device__ __noinline__ Fp fsqr(Fp a) { return fe_mul(a, a); }
+static __device__ __noinline__ Fp fmul(Fp a, Fp b) { return fe_mul_fips(a, b); }
+static __device__ __noinline__ Fp fsqr(Fp a) { return fe_mul_fips(a, a); }
 #else
-KZG_DEV Fp fmul(const Fp& a, const Fp& b) { return fe_mul(a, b); }
-KZG_DEV Fp fsqr(const Fp& a) { return fe_mul(a, a); }
+KZG_DEV Fp fmul(const Fp& a, const Fp& b) { return fe_mul_fips(a, b); }
+KZG_DEV Fp fsqr(const Fp& a) { return fe_mul_fips(a, a); }
 #endif
 
 struct Affine {  // Montgomery x, y;  (0, 0) encodes the point at infinity (it is not on the curve)

@@ -160,6 +160,29 @@ __global__ void __launch_bounds__(256) k_fpmul(u32* io, int iters) {
     if (x.l[3] == 0x12345 && y.l[2] == 77) io[48] = 1;  // keep live for all threads
 }
 
+__global__ void __launch_bounds__(256) k_fpmul_fips(u32* io, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x, y;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        x.l[i] = io[i];
+        y.l[i] = io[12 + i];
+    }
+    x.l[0] ^= (tid & 0xff);
+    for (int it = 0; it < iters; it++) {
+        x = fe_mul_fips(x, y);
+        y = fe_mul_fips(y, x);
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            io[24 + i] = x.l[i];
+            io[36 + i] = y.l[i];
+        }
+    }
+    if (x.l[3] == 0x12345 && y.l[2] == 77) io[48] = 1;
+}
+
 __global__ void __launch_bounds__(256) k_frmul(u32* io, int iters) {
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
     Fr x, y;
@@ -299,6 +322,9 @@ int main() {
         double ms = time_kernel(k_fpmul, grid, block, 3, dio, fit);
         double nmul = (double)grid * block * fit * 2;
         printf("{\"bench\": \"fp_mul\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gmul_s\": %.2f}\n", wps, ms, nmul / ms / 1e6);
+        ms = time_kernel(k_fpmul_fips, grid, block, 3, dio, fit);
+        printf("{\"bench\": \"fp_mul_fips\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gmul_s\": %.2f}\n", wps, ms, nmul / ms / 1e6);
+        CHECK(hipMemcpy(dio, h, sizeof h, hipMemcpyHostToDevice));
         ms = time_kernel(k_frmul, grid, block, 3, dio, fit);
         printf("{\"bench\": \"fr_mul\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gmul_s\": %.2f}\n", wps, ms, nmul / ms / 1e6);
         CHECK(hipMemcpy(dio, h, sizeof h, hipMemcpyHostToDevice));
@@ -315,6 +341,20 @@ int main() {
     CHECK(hipMemcpy(dio, h, sizeof h, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_fpmul, dim3(1), dim3(64), 0, 0, dio, 3);
     CHECK(hipMemcpy(h, dio, sizeof h, hipMemcpyDeviceToHost));
+    {
+        u32 h2[128];
+        memset(h2, 0, sizeof h2);
+        memcpy(h2, GX, 48);
+        memcpy(h2 + 12, GY, 48);
+        CHECK(hipMemcpy(dio, h2, sizeof h2, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_fpmul_fips, dim3(1), dim3(64), 0, 0, dio, 3);
+        CHECK(hipMemcpy(h2, dio, sizeof h2, hipMemcpyDeviceToHost));
+        printf("{\"probe\": \"fpmul3_fips\", ");
+        hexout("x", h2 + 24, 12);
+        printf(", ");
+        hexout("y", h2 + 36, 12);
+        printf("}\n");
+    }
     printf("{\"probe\": \"fpmul3\", ");
     hexout("x", h + 24, 12);
     printf(", ");
