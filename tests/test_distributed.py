@@ -1,0 +1,77 @@
+"""CPU, world_size 2, gloo: the N > 1 path of bench.py / sharding.py -- SRS-range partition, all-gather
+of one blst_p1 partial per rank, K-1 complete additions on every rank (kzg_g1_sum, host side of the
+C-ABI).  The per-rank device MSM is stood in for by the oracle (this is a test: the oracle is the
+checker and the stand-in, never the product), so the exchange and the combine run exactly as they do
+on RCCL, just over gloo."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+
+    import bigint_twin as T
+    import kzg_poly_commit_exploration_amd as K
+    import oracle_ctypes as O
+    from kzg_poly_commit_exploration_amd.sharding import allgather_partials, combine, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(n, rank, world)
+        # this rank's SRS slice and coefficient slice (what kzg_srs_generate_g1(first=lo) holds on a GPU)
+        srs = np.stack([O.srs_g1_at(k, T.BENCH_SECRET_BE) for k in range(lo, hi)]) if hi > lo else O.p1_zeros(0)
+        c = O.bench_coefficients(n)[lo:hi]
+        rc, partial = O.commit_naive(c, srs) if hi > lo else (0, np.zeros(18, dtype=np.uint64))
+        assert rc == 0
+        total = combine(allgather_partials(K.G1Point(partial)))
+        out_q.put((rank, total.compress().hex()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [101, 2])
+def test_two_rank_sharded_commit_over_gloo(golden, n):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = next(b["commit"] for b in golden["bench"] if b["degree"] == n - 1)
+    assert got[0] == want and got[1] == want
+
+
+def test_shard_ranges_cover_everything():
+    sys.path.insert(0, ROOT)
+    from kzg_poly_commit_exploration_amd.sharding import shard_range
+
+    for n in (0, 1, 7, 8, 9, (1 << 20) + 1, (1 << 22) + 1):
+        for world in (1, 2, 4, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b and c <= d

@@ -347,3 +347,23 @@ def test_degree_2_20_commit_and_proof_golden(engines, oracle, golden):
     q = eng.quotient_limbs(c, z, y)
     rc, q_want = oracle.quotient(c, oracle.fr_from_int(z.v), oracle.fr_from_int(y.v))
     assert rc == 0 and np.array_equal(q, q_want)
+
+
+# ---------------------------------------------------------------- C++ host mirror over the same C-ABI
+
+def test_cpp_mirror_example(twin):
+    """examples/commit_open.cpp (include/kzg_mi355x.hpp): P = 1 + x over the bench SRS, opened at z = 1."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "commit_open")
+    if not os.path.exists(exe):
+        pytest.skip("examples/commit_open not built (run __graft_entry__.build())")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.split()
+    s = twin.fr_from_be_bytes(twin.BENCH_SECRET_BE)
+    assert lines[0:2] == ["degree", "1"]
+    assert lines[2] == twin.g1_compress(twin.g1_mul(twin.G1, (1 + s) % twin.R)).hex()
+    assert lines[3] == twin.g1_compress(twin.G1).hex()  # (P - 2)/(x - 1) = 1
