@@ -47,8 +47,9 @@ struct Slot {
     hipEvent_t ev[8] = {};
     hipEvent_t done = nullptr;
     // MSM workspace (sized at SRS load)
-    uint32_t *d_hist = nullptr, *d_offs = nullptr, *d_block_sums = nullptr;
-    uint32_t *d_rank = nullptr, *d_sorted = nullptr;
+    uint32_t *d_cnt = nullptr, *d_offs = nullptr, *d_block_sums = nullptr;
+    uint64_t* d_pairs = nullptr;
+    uint32_t* d_sorted = nullptr;
     void* d_buckets = nullptr;
     void *d_part_a = nullptr, *d_part_b = nullptr;  // head / tail partials of the accumulation segments
     uint32_t* d_heavy_list = nullptr;
@@ -103,10 +104,11 @@ namespace {
     } while (0)
 
 void free_slot_msm(Slot& s) {
-    hipFree(s.d_hist); hipFree(s.d_offs); hipFree(s.d_block_sums); hipFree(s.d_rank); hipFree(s.d_sorted);
+    hipFree(s.d_cnt); hipFree(s.d_offs); hipFree(s.d_block_sums); hipFree(s.d_pairs); hipFree(s.d_sorted);
     hipFree(s.d_buckets); hipFree(s.d_part_a); hipFree(s.d_part_b); hipFree(s.d_heavy_list); hipFree(s.d_arena); hipFree(s.d_sumtmp[0]); hipFree(s.d_sumtmp[1]); hipFree(s.d_final);
     if (s.h_final) hipHostFree(s.h_final);
-    s.d_hist = s.d_offs = s.d_block_sums = s.d_rank = s.d_sorted = nullptr;
+    s.d_cnt = s.d_offs = s.d_block_sums = s.d_sorted = nullptr;
+    s.d_pairs = nullptr;
     s.d_buckets = s.d_part_a = s.d_part_b = s.d_arena = s.d_sumtmp[0] = s.d_sumtmp[1] = s.d_final = nullptr;
     s.d_heavy_list = nullptr;
     s.h_final = nullptr;
@@ -177,10 +179,10 @@ int setup_slots(kzg_ctx* ctx) {
             HIP_TRY(ctx, hipHostMalloc(&s.h_small, 64 * 4));
         }
         free_slot_msm(s);
-        HIP_TRY(ctx, hipMalloc(&s.d_hist, (size_t)cfg.nb * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_cnt, (size_t)sort_count_entries((uint32_t)ctx->n, cfg) * 4 + 64));
         HIP_TRY(ctx, hipMalloc(&s.d_offs, ((size_t)cfg.nb + 1) * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_block_sums, 1024 * 4));
-        HIP_TRY(ctx, hipMalloc(&s.d_rank, (pairs ? pairs : 1) * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_pairs, (pairs ? pairs : 1) * 8));
         HIP_TRY(ctx, hipMalloc(&s.d_sorted, (pairs ? pairs : 1) * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_buckets, (size_t)cfg.nb * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_part_a, (size_t)kMaxAccumLanes * kXyzzBytes));
@@ -237,13 +239,13 @@ int srs_prepare(kzg_ctx* ctx, size_t n) {
 int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, size_t n, int ev_base) {
     const MsmConfig cfg = ctx->cfg;
     hipStream_t st = s.stream;
-    HIP_TRY(ctx, hipMemsetAsync(s.d_hist, 0, (size_t)cfg.nb * 4, st));
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base], st));
-    launch_digits_hist(st, d_scalars, is_mont, (uint32_t)n, cfg, s.d_hist, s.d_rank);
-    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 1], st));
-    launch_bucket_scan(st, s.d_hist, cfg.nb, s.d_offs, s.d_block_sums);
-    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 2], st));
-    launch_scatter(st, d_scalars, is_mont, (uint32_t)n, (uint32_t)ctx->n, cfg, s.d_offs, s.d_rank, s.d_sorted);
+    launch_bucket_sort(st, d_scalars, is_mont, (uint32_t)n, (uint32_t)ctx->n, cfg, s.d_cnt, s.d_block_sums, s.d_pairs,
+                       s.d_offs, s.d_sorted);
+    if (s.timing) {
+        HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 1], st));
+        HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 2], st));
+    }
     const uint64_t max_refs = (uint64_t)n * cfg.W;
     const uint32_t L = accumulate_segment_len(max_refs);
     HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)cfg.nb * kXyzzBytes, st));  // zero = infinity

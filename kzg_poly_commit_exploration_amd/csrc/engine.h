@@ -24,17 +24,13 @@ struct MsmConfig {
 MsmConfig choose_msm_config(size_t n_points);
 
 // ---- msm_kernels.hip --------------------------------------------------------------------
-// pass 1: recode every scalar into W signed digits, histogram the buckets, remember each
-// (scalar, window) pair's arrival rank inside its bucket.
-void launch_digits_hist(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n,
-                        MsmConfig cfg, uint32_t* d_hist, uint32_t* d_rank);
-// exclusive prefix sum of the bucket histogram -> d_offs[0..nb] (d_offs[nb] = number of pairs)
-void launch_bucket_scan(hipStream_t s, const uint32_t* d_hist, uint32_t nb, uint32_t* d_offs,
-                        uint32_t* d_block_sums);
-// pass 2: counting-sort scatter of (table index | sign << 31) into bucket-major order
-void launch_scatter(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n,
-                    uint32_t table_stride, MsmConfig cfg, const uint32_t* d_offs, const uint32_t* d_rank,
-                    uint32_t* d_sorted);
+// scalar recoding + two-level LDS counting sort: fills d_offs[0..nb] (d_offs[nb] = number of
+// references) and d_sorted (bucket-major table references, index | sign << 31).
+//   d_cnt: sort_count_entries(n_max, cfg) u32;  d_block_sums: 1024 u32;  d_pairs: n * W u64
+uint32_t sort_count_entries(uint32_t n, MsmConfig cfg);
+void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n,
+                        uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt, uint32_t* d_block_sums,
+                        uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted);
 // bucket accumulation (dominant kernel): one lane per segment of L sorted references
 constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on ceil(max_refs / accumulate_segment_len(max_refs))
 uint32_t accumulate_segment_len(uint64_t max_refs);

@@ -3,9 +3,9 @@
 // blst_p1_mult window walk of the reference (src/scalar.rs:83-93, src/curves.rs:90-96) for the
 // whole polynomial at once.
 //
-// HBM traffic per commitment of n terms, W windows: scalars read twice (2 x 32 B x n), ranks
-// written + read (2 x 4 B x n x W), references written (4 B x n x W), histogram atomics (n x W).
-// This is integer / byte work bound by scattered 4-byte accesses, not by arithmetic.
+// HBM traffic per commitment of n terms, W windows: scalars read twice (2 x 32 B x n), pairs written
+// once and read twice (3 x 8 B x n x W), references written (4 B x n x W).  Integer / byte work bound
+// by LDS atomics and scattered 4..8-byte stores, not by arithmetic.
 #include "engine.h"
 #include "field.hip.h"
 
@@ -86,31 +86,127 @@ KZG_DEV void for_each_digit(u32 k[8], uint32_t c, uint32_t W, F&& f) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_digits_hist(const uint32_t* __restrict__ d_scalars, int is_mont, uint32_t n,
-                                                     uint32_t c, uint32_t W, uint32_t* __restrict__ d_hist,
-                                                     uint32_t* __restrict__ d_rank) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 k[8];
-    (void)load_scalar(d_scalars, i, is_mont, k);
-    for_each_digit(k, c, W, [&](uint32_t j, u32 mag, bool) {
-        u32 r = atomicAdd(&d_hist[mag - 1], 1u);
-        d_rank[(size_t)j * n + i] = r;
-    });
+// ---- two-level counting sort of the (scalar, window) pairs by bucket -------------------------
+// Scattered global atomics cap out near 2e10/s on MI355X (they execute at the memory side), which made
+// the histogram the second most expensive kernel.  The sort is therefore staged through LDS:
+//   pass 1  every workgroup takes a tile of scalars, recodes them and histograms the COARSE bin
+//           (bucket >> fine_bits) of each digit in LDS; counts go out bin-major [bin][tile]
+//   scan    exclusive scan of that table: where each tile writes inside each coarse bin
+//   pass 2  same recoding; LDS cursors hand out positions; (fine key, table reference) pairs are
+//           written into their coarse bin
+//   pass 3  one workgroup per coarse bin: LDS histogram of the fine key -> bucket offsets, then the
+//           references are moved to their final, bucket-major position
+// No global atomics, no rank array; order inside a bucket is arbitrary (the group law is commutative,
+// the result is bit-identical).
+constexpr int kSortBlock = 1024;
+constexpr int kMaxCoarse = 2048;
+constexpr int kFineMax = 256;
+
+struct SortGeom {
+    uint32_t tile;         // scalars per workgroup in passes 1/2
+    uint32_t tiles;        // workgroups
+    uint32_t fine_bits;    // low bits of the bucket id resolved in pass 3
+    uint32_t coarse_bins;  // nb >> fine_bits
+};
+
+static SortGeom sort_geometry(uint32_t n, MsmConfig cfg) {
+    SortGeom g;
+    uint32_t tile = (n + 255) / 256;                      // at most 256 tiles
+    tile = ((tile + kSortBlock - 1) / kSortBlock) * kSortBlock;
+    if (tile < (uint32_t)kSortBlock) tile = kSortBlock;
+    g.tile = tile;
+    g.tiles = (n + tile - 1) / tile;
+    g.fine_bits = cfg.c - 1 < 8 ? cfg.c - 1 : 8;
+    g.coarse_bins = cfg.nb >> g.fine_bits;
+    return g;
 }
 
-__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ d_scalars, int is_mont, uint32_t n,
-                                                 uint32_t table_stride, uint32_t c, uint32_t W,
-                                                 const uint32_t* __restrict__ d_offs,
-                                                 const uint32_t* __restrict__ d_rank, uint32_t* __restrict__ d_sorted) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 k[8];
-    const bool flip = load_scalar(d_scalars, i, is_mont, k);
-    for_each_digit(k, c, W, [&](uint32_t j, u32 mag, bool neg) {
-        u32 pos = d_offs[mag - 1] + d_rank[(size_t)j * n + i];
-        d_sorted[pos] = (j * table_stride + i) | ((neg != flip) ? 0x80000000u : 0u);
-    });
+uint32_t sort_count_entries(uint32_t n, MsmConfig cfg) {
+    // a commitment shorter than the SRS may use more (smaller) tiles than the full length: bound by 256
+    SortGeom g = sort_geometry(n, cfg);
+    return g.coarse_bins * 257u;
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_sort_count(const uint32_t* __restrict__ d_scalars, int is_mont,
+                                                           uint32_t n, uint32_t c, uint32_t W, uint32_t tile,
+                                                           uint32_t tiles, uint32_t fine_bits, uint32_t coarse_bins,
+                                                           uint32_t* __restrict__ d_cnt) {
+    __shared__ u32 s_hist[kMaxCoarse];
+    for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) s_hist[q] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * tile;
+    for (uint32_t off = threadIdx.x; off < tile; off += kSortBlock) {
+        uint32_t i = base + off;
+        if (i >= n) break;
+        u32 k[8];
+        (void)load_scalar(d_scalars, i, is_mont, k);
+        for_each_digit(k, c, W, [&](uint32_t, u32 mag, bool) { atomicAdd(&s_hist[(mag - 1) >> fine_bits], 1u); });
+    }
+    __syncthreads();
+    for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) d_cnt[(size_t)q * tiles + blockIdx.x] = s_hist[q];
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_sort_spread(const uint32_t* __restrict__ d_scalars, int is_mont,
+                                                            uint32_t n, uint32_t table_stride, uint32_t c, uint32_t W,
+                                                            uint32_t tile, uint32_t tiles, uint32_t fine_bits,
+                                                            uint32_t coarse_bins, const uint32_t* __restrict__ d_cnt_scanned,
+                                                            uint64_t* __restrict__ d_pairs) {
+    __shared__ u32 s_cur[kMaxCoarse];
+    for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) s_cur[q] = d_cnt_scanned[(size_t)q * tiles + blockIdx.x];
+    __syncthreads();
+    const uint32_t base = blockIdx.x * tile;
+    const u32 fine_mask = (1u << fine_bits) - 1u;
+    for (uint32_t off = threadIdx.x; off < tile; off += kSortBlock) {
+        uint32_t i = base + off;
+        if (i >= n) break;
+        u32 k[8];
+        const bool flip = load_scalar(d_scalars, i, is_mont, k);
+        for_each_digit(k, c, W, [&](uint32_t j, u32 mag, bool neg) {
+            u32 b = mag - 1;
+            u32 pos = atomicAdd(&s_cur[b >> fine_bits], 1u);
+            u32 ref = (j * table_stride + i) | ((neg != flip) ? 0x80000000u : 0u);
+            d_pairs[pos] = ((uint64_t)(b & fine_mask) << 32) | ref;
+        });
+    }
+}
+
+// one workgroup per coarse bin: [rs, re) of d_pairs -> bucket offsets + bucket-major references
+__global__ void __launch_bounds__(kSortBlock) k_sort_fine(const uint64_t* __restrict__ d_pairs,
+                                                          const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
+                                                          uint32_t fine_bits, uint32_t coarse_bins,
+                                                          const uint32_t* __restrict__ d_total,
+                                                          uint32_t* __restrict__ d_offs, uint32_t* __restrict__ d_sorted) {
+    __shared__ u32 s_hist[kFineMax];
+    __shared__ u32 s_scan[kFineMax];
+    const uint32_t bin = blockIdx.x;
+    const uint32_t fine = 1u << fine_bits;
+    const uint32_t rs = d_cnt_scanned[(size_t)bin * tiles];
+    const uint32_t re = (bin + 1 < coarse_bins) ? d_cnt_scanned[(size_t)(bin + 1) * tiles] : *d_total;
+    if (threadIdx.x < fine) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t e = rs + threadIdx.x; e < re; e += kSortBlock) atomicAdd(&s_hist[(u32)(d_pairs[e] >> 32)], 1u);
+    __syncthreads();
+    // exclusive scan of <= 256 counts (Hillis-Steele on the first `fine` lanes)
+    u32 v = threadIdx.x < fine ? s_hist[threadIdx.x] : 0u;
+    if (threadIdx.x < (u32)kFineMax) s_scan[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < fine; off <<= 1) {
+        u32 add = (threadIdx.x < fine && threadIdx.x >= off) ? s_scan[threadIdx.x - off] : 0u;
+        __syncthreads();
+        if (threadIdx.x < fine) s_scan[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if (threadIdx.x < fine) {
+        u32 ex = s_scan[threadIdx.x] - v;
+        d_offs[(bin << fine_bits) + threadIdx.x] = rs + ex;
+        s_hist[threadIdx.x] = rs + ex;  // becomes the cursor
+    }
+    __syncthreads();
+    for (uint32_t e = rs + threadIdx.x; e < re; e += kSortBlock) {
+        uint64_t pr = d_pairs[e];
+        u32 pos = atomicAdd(&s_hist[(u32)(pr >> 32)], 1u);
+        d_sorted[pos] = (u32)pr;
+    }
 }
 
 // ---- exclusive scan of the histogram (<= 2^20 buckets): local / top / add -----------------
@@ -181,26 +277,26 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ 
         if (base + t < nb) d_offs[base + t] += add;
 }
 
-void launch_digits_hist(hipStream_t s, const uint32_t* d_scalars, int is_mont, uint32_t n, MsmConfig cfg,
-                        uint32_t* d_hist, uint32_t* d_rank) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(k_digits_hist, dim3((n + 255) / 256), dim3(256), 0, s, d_scalars, is_mont, n, cfg.c, cfg.W,
-                       d_hist, d_rank);
+// exclusive scan of `count` u32 (count <= 2^20) in place: d_buf -> offsets, total -> *d_total
+static void scan_inplace(hipStream_t s, uint32_t* d_buf, uint32_t count, uint32_t* d_block_sums, uint32_t* d_total) {
+    uint32_t nblocks = (count + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(kScanBlock), 0, s, d_buf, count, d_buf, d_block_sums);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, d_block_sums, nblocks, d_total);
+    hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(kScanBlock), 0, s, d_buf, count, d_block_sums);
 }
 
-void launch_bucket_scan(hipStream_t s, const uint32_t* d_hist, uint32_t nb, uint32_t* d_offs,
-                        uint32_t* d_block_sums) {
-    uint32_t nblocks = (nb + kScanTile - 1) / kScanTile;  // <= 1024 for nb <= 2^20
-    hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(kScanBlock), 0, s, d_hist, nb, d_offs, d_block_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, d_block_sums, nblocks, d_offs + nb);
-    hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(kScanBlock), 0, s, d_offs, nb, d_block_sums);
-}
-
-void launch_scatter(hipStream_t s, const uint32_t* d_scalars, int is_mont, uint32_t n, uint32_t table_stride,
-                    MsmConfig cfg, const uint32_t* d_offs, const uint32_t* d_rank, uint32_t* d_sorted) {
+void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, uint32_t n, uint32_t table_stride,
+                        MsmConfig cfg, uint32_t* d_cnt, uint32_t* d_block_sums, uint64_t* d_pairs, uint32_t* d_offs,
+                        uint32_t* d_sorted) {
     if (n == 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3((n + 255) / 256), dim3(256), 0, s, d_scalars, is_mont, n, table_stride, cfg.c,
-                       cfg.W, d_offs, d_rank, d_sorted);
+    SortGeom g = sort_geometry(n, cfg);
+    hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, n, cfg.c, cfg.W, g.tile,
+                       g.tiles, g.fine_bits, g.coarse_bins, d_cnt);
+    scan_inplace(s, d_cnt, g.coarse_bins * g.tiles, d_block_sums, d_offs + cfg.nb);  // total pairs -> offs[nb]
+    hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, n, table_stride, cfg.c,
+                       cfg.W, g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_pairs);
+    hipLaunchKernelGGL(k_sort_fine, dim3(g.coarse_bins), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
+                       g.coarse_bins, d_offs + cfg.nb, d_offs, d_sorted);
 }
 
 }  // namespace kzg
