@@ -215,6 +215,12 @@ def main():
         achieved = algo_bytes / (avg_accum_ms * 1e-3) / 1e9 if avg_accum_ms > 0 else 0.0
         madds = n_mine * cfg["windows"]            # one mixed addition per (term, window) pair (zero digits aside)
         tmad = madds * MADS_PER_MADD / (avg_accum_ms * 1e-3) / 1e12 if avg_accum_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+        if world == 1 and degree == DEGREE and os.path.exists(tpath):
+            # PMC bytes of the same kernel on the same workload, measured off-line by tools/prof_pmc.sh
+            with open(tpath) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
         line = {
             "metric": "g1_msm_commitments_per_sec_degree_2^20",
             "value": args.steps / elapsed,
@@ -234,7 +240,7 @@ def main():
                        "windows": cfg["windows"], "buckets": cfg["buckets"], "stream_slots": slots,
                        "bit_exact_vs_golden": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_bucket_accumulate", "avg_kernel_ms": avg_accum_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "integer-multiply (VALU) bound by construction: see valu"},

@@ -253,6 +253,27 @@ __global__ void __launch_bounds__(256) k_add(u32* io, int iters) {
     if (acc.X.l[3] == 0x12345 && acc.Y.l[2] == 77) io[80] = 1;
 }
 
+// calibration of the rocprofv3 FETCH_SIZE counter on the accumulation kernel's access pattern:
+// every lane reads `iters` random 96-byte records (6 x dwordx4) from a table larger than the
+// Infinity Cache.  Requested bytes are known: lanes * iters * 96.
+__global__ void __launch_bounds__(256) k_gather96(const uint4* __restrict__ table, uint32_t records, int iters,
+                                                  u64* out) {
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t state = tid * 2654435761u + 12345u;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int it = 0; it < iters; it++) {
+        state = state * 1664525u + 1013904223u;
+        uint32_t idx = (uint32_t)(((u64)state * records) >> 32);
+        const uint4* p = table + (size_t)idx * 6;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            uint4 v = p[q];
+            acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+        }
+    }
+    out[tid] = (u64)acc.x ^ acc.y ^ ((u64)(acc.z ^ acc.w) << 32);
+}
+
 template <class K, class... A>
 static double time_kernel(K kern, int grid, int block, int reps, A... args) {
     hipEvent_t e0, e1;
@@ -275,7 +296,23 @@ static void hexout(const char* name, const u32* l, int n) {
     printf("\"");
 }
 
-int main() {
+static int run_gather_calibration() {
+    const uint32_t records = 15u * 1048577u;  // the 2^20 window table: 1.41 GiB
+    uint4* table;
+    u64* out;
+    CHECK(hipMalloc(&table, (size_t)records * 96));
+    CHECK(hipMemset(table, 0x5a, (size_t)records * 96));
+    const int lanes = 262144, iters = 60;
+    CHECK(hipMalloc(&out, sizeof(u64) * lanes));
+    double ms = time_kernel(k_gather96, lanes / 256, 256, 3, (const uint4*)table, records, iters, out);
+    double bytes = (double)lanes * iters * 96.0;
+    printf("{\"bench\": \"gather96\", \"requested_bytes_per_launch\": %.0f, \"ms\": %.4f, \"GBs\": %.1f}\n", bytes, ms,
+           bytes / ms / 1e6);
+    return 0;
+}
+
+int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "gather")) return run_gather_calibration();
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     int cus = prop.multiProcessorCount;
