@@ -4,8 +4,8 @@
 //
 // One commitment on a slot's stream:
 //   memset(hist) -> digits+histogram -> scan -> scatter -> bucket accumulation
-//   -> weighted running-sum levels (+ plain chunk sums of each level's acc[]) -> D2H of <= a few
-//   hundred XYZZ partials -> host: Horner over the levels, normalise, blst_p1 out.
+//   -> bucket finalisation -> row / column tree sums of the bucket matrix, split once more
+//   -> D2H of <= 128 XYZZ partials -> host: four short weighted sums, normalise, blst_p1 out.
 // Nothing here falls back to the CPU for the MSM or the division: without a device the context
 // cannot be created.
 #include <hip/hip_runtime.h>
@@ -27,17 +27,14 @@ namespace hf = kzg_host;
 namespace {
 
 constexpr int kNumSlots = 3;
-constexpr uint32_t kWsumM = 4;      // chunk of the weighted running-sum levels
-constexpr uint32_t kSumM = 8;       // fan-in of the plain chunk sums
-constexpr uint32_t kFinalMax = 32;  // partials per level handed to the host
-
-struct Level {
-    uint32_t n_items;   // items entering the level
-    uint32_t chunks;    // = ceil(n_items / kWsumM): size of acc[] and run[]
-    size_t acc_off;     // XYZZ record offsets into the reduce arena
-    size_t run_off;
-    uint32_t n_final;   // partials of this level copied to the host
-    size_t final_off;   // record offset in the final buffer
+// Reduction plan (msm_reduce.hip): bucket index b = hi * C + lo; Row (R entries) and Col (C entries)
+// are each split once more into a "row" part and a "column" part that the host receives.
+struct ReducePlan {
+    uint32_t lo_bits = 0, hi_bits = 0;  // C = 2^lo_bits, R = 2^hi_bits
+    uint32_t row_lo = 0, row_hi = 0;    // split of the Row vector index (hi_bits = row_lo + row_hi)
+    uint32_t col_lo = 0, col_hi = 0;    // split of the Col vector index (lo_bits = col_lo + col_hi)
+    // record offsets inside the final buffer
+    uint32_t off_r2row = 0, off_c2row = 0, off_r2col = 0, off_c2col = 0, total = 0;
 };
 
 enum SlotKind { SLOT_IDLE = 0, SLOT_COMMIT = 1, SLOT_OPEN = 2, SLOT_TRIVIAL = 3 };
@@ -53,8 +50,7 @@ struct Slot {
     void* d_buckets = nullptr;
     void *d_part_a = nullptr, *d_part_b = nullptr;  // head / tail partials of the accumulation segments
     uint32_t* d_heavy_list = nullptr;
-    void* d_arena = nullptr;     // acc[] / run[] of every level
-    void* d_sumtmp[2] = {nullptr, nullptr};
+    void* d_arena = nullptr;     // Row[] then Col[] vectors of the bucket matrix
     void* d_final = nullptr;
     uint64_t* h_final = nullptr;  // pinned
     // polynomial workspace (grown on demand)
@@ -85,8 +81,8 @@ struct kzg_ctx {
     size_t n = 0;  // points
     MsmConfig cfg = {};
     void* d_table = nullptr;  // W * n affine points
-    std::vector<Level> levels;
-    size_t arena_records = 0, final_records = 0, sumtmp_records = 0;
+    ReducePlan plan;
+    size_t arena_records = 0, final_records = 0;
     Slot slots[kNumSlots];
     bool slots_ready = false;
     bool timing = false;
@@ -105,11 +101,11 @@ namespace {
 
 void free_slot_msm(Slot& s) {
     hipFree(s.d_cnt); hipFree(s.d_offs); hipFree(s.d_block_sums); hipFree(s.d_pairs); hipFree(s.d_sorted);
-    hipFree(s.d_buckets); hipFree(s.d_part_a); hipFree(s.d_part_b); hipFree(s.d_heavy_list); hipFree(s.d_arena); hipFree(s.d_sumtmp[0]); hipFree(s.d_sumtmp[1]); hipFree(s.d_final);
+    hipFree(s.d_buckets); hipFree(s.d_part_a); hipFree(s.d_part_b); hipFree(s.d_heavy_list); hipFree(s.d_arena); hipFree(s.d_final);
     if (s.h_final) hipHostFree(s.h_final);
     s.d_cnt = s.d_offs = s.d_block_sums = s.d_sorted = nullptr;
     s.d_pairs = nullptr;
-    s.d_buckets = s.d_part_a = s.d_part_b = s.d_arena = s.d_sumtmp[0] = s.d_sumtmp[1] = s.d_final = nullptr;
+    s.d_buckets = s.d_part_a = s.d_part_b = s.d_arena = s.d_final = nullptr;
     s.d_heavy_list = nullptr;
     s.h_final = nullptr;
 }
@@ -133,40 +129,27 @@ int ensure_poly(kzg_ctx* ctx, Slot& s, size_t n) {
 }
 
 // reduction plan: depends only on the bucket count
-void plan_levels(kzg_ctx* ctx) {
-    ctx->levels.clear();
-    size_t arena = 0, fin = 0;
-    uint32_t n_items = ctx->cfg.nb;
-    size_t sumtmp = 0;
-    while (true) {
-        Level L;
-        L.n_items = n_items;
-        L.chunks = (n_items + kWsumM - 1) / kWsumM;
-        L.acc_off = arena;
-        arena += L.chunks;
-        L.run_off = arena;
-        arena += L.chunks;
-        uint32_t cnt = L.chunks;
-        bool first = true;
-        while (cnt > kFinalMax) {
-            cnt = (cnt + kSumM - 1) / kSumM;
-            if (first && cnt > sumtmp) sumtmp = cnt;
-            first = false;
-        }
-        L.n_final = cnt;
-        L.final_off = fin;
-        fin += cnt;
-        ctx->levels.push_back(L);
-        if (L.chunks <= 1) break;
-        n_items = L.chunks - 1;  // run[1..] carry weights 1..
-    }
-    ctx->arena_records = arena;
-    ctx->final_records = fin;
-    ctx->sumtmp_records = sumtmp ? sumtmp : 1;
+void plan_reduce(kzg_ctx* ctx) {
+    ReducePlan P;
+    uint32_t bits = ctx->cfg.c - 1;
+    P.lo_bits = bits / 2;
+    P.hi_bits = bits - P.lo_bits;
+    P.row_lo = P.hi_bits / 2;
+    P.row_hi = P.hi_bits - P.row_lo;
+    P.col_lo = P.lo_bits / 2;
+    P.col_hi = P.lo_bits - P.col_lo;
+    P.off_r2row = 0;
+    P.off_c2row = P.off_r2row + (1u << P.row_hi);
+    P.off_r2col = P.off_c2row + (1u << P.row_lo);
+    P.off_c2col = P.off_r2col + (1u << P.col_hi);
+    P.total = P.off_c2col + (1u << P.col_lo);
+    ctx->plan = P;
+    ctx->arena_records = ((size_t)1 << P.hi_bits) + ((size_t)1 << P.lo_bits);
+    ctx->final_records = P.total;
 }
 
 int setup_slots(kzg_ctx* ctx) {
-    plan_levels(ctx);
+    plan_reduce(ctx);
     const MsmConfig cfg = ctx->cfg;
     const size_t pairs = (size_t)cfg.W * ctx->n;
     for (int i = 0; i < kNumSlots; i++) {
@@ -189,8 +172,6 @@ int setup_slots(kzg_ctx* ctx) {
         HIP_TRY(ctx, hipMalloc(&s.d_part_b, (size_t)kMaxAccumLanes * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_heavy_list, (size_t)cfg.nb * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_arena, ctx->arena_records * kXyzzBytes));
-        HIP_TRY(ctx, hipMalloc(&s.d_sumtmp[0], ctx->sumtmp_records * kXyzzBytes));
-        HIP_TRY(ctx, hipMalloc(&s.d_sumtmp[1], ctx->sumtmp_records * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_final, ctx->final_records * kXyzzBytes));
         HIP_TRY(ctx, hipHostMalloc(&s.h_final, ctx->final_records * kXyzzBytes));
         s.kind = SLOT_IDLE;
@@ -256,25 +237,20 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], st));
     launch_bucket_finalize(st, s.d_offs, cfg.nb, L, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_list,
                            s.d_small + 25);
-    // reduction levels
-    const char* items = (const char*)s.d_buckets;
-    for (size_t li = 0; li < ctx->levels.size(); li++) {
-        const Level& L = ctx->levels[li];
-        char* acc = (char*)s.d_arena + L.acc_off * kXyzzBytes;
-        char* run = (char*)s.d_arena + L.run_off * kXyzzBytes;
-        launch_wsum_level(st, items, L.n_items, kWsumM, acc, run);
-        const char* cur = acc;
-        uint32_t cnt = L.chunks;
-        int pp = 0;
-        while (cnt > kFinalMax) {
-            launch_sum_level(st, cur, cnt, kSumM, s.d_sumtmp[pp]);
-            cur = (const char*)s.d_sumtmp[pp];
-            cnt = (cnt + kSumM - 1) / kSumM;
-            pp ^= 1;
-        }
-        HIP_TRY(ctx, hipMemcpyAsync((char*)s.d_final + L.final_off * kXyzzBytes, cur, (size_t)cnt * kXyzzBytes,
-                                    hipMemcpyDeviceToDevice, st));
-        items = run + kXyzzBytes;  // run[1..]
+    // reduction: Row / Col tree sums of the bucket matrix, each split once more
+    {
+        const ReducePlan& P = ctx->plan;
+        const uint32_t R = 1u << P.hi_bits, C = 1u << P.lo_bits;
+        char* row = (char*)s.d_arena;
+        char* col = row + (size_t)R * kXyzzBytes;
+        char* fin = (char*)s.d_final;
+        launch_tree_sum(st, s.d_buckets, R, C, C, 1, row);  // Row[hi] = sum_lo B[hi*C + lo]
+        launch_tree_sum(st, s.d_buckets, C, R, 1, C, col);  // Col[lo] = sum_hi B[hi*C + lo]
+        const uint32_t rl = 1u << P.row_lo, rh = 1u << P.row_hi, cl = 1u << P.col_lo, ch = 1u << P.col_hi;
+        launch_tree_sum(st, row, rh, rl, rl, 1, fin + (size_t)P.off_r2row * kXyzzBytes);
+        launch_tree_sum(st, row, rl, rh, 1, rl, fin + (size_t)P.off_c2row * kXyzzBytes);
+        launch_tree_sum(st, col, ch, cl, cl, 1, fin + (size_t)P.off_r2col * kXyzzBytes);
+        launch_tree_sum(st, col, cl, ch, 1, cl, fin + (size_t)P.off_c2col * kXyzzBytes);
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 5], st));
     HIP_TRY(ctx, hipMemcpyAsync(s.h_final, s.d_final, ctx->final_records * kXyzzBytes, hipMemcpyDeviceToHost, st));
@@ -282,18 +258,34 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
     return KZG_OK;
 }
 
-// host tail: total = A_0 + m (A_1 + m (A_2 + ...)),  A_l = sum of level l's partials
-hf::P1 finish_msm(const kzg_ctx* ctx, const Slot& s) {
-    hf::P1 acc = hf::p1_inf();
-    uint32_t log_m = 0;
-    while ((1u << log_m) < kWsumM) log_m++;
-    for (size_t li = ctx->levels.size(); li-- > 0;) {
-        const Level& L = ctx->levels[li];
-        for (uint32_t k = 0; k < log_m; k++) acc = hf::p1_double(acc);
-        for (uint32_t k = 0; k < L.n_final; k++)
-            acc = hf::p1_add(acc, hf::p1_from_xyzz(s.h_final + (L.final_off + k) * kXyzzWords64));
+// host tail.  With V indexed by u = u1 * 2^lo + u0:  sum_u u V_u = 2^lo * wsum(R2) + wsum(C2), where
+// R2[u1] = sum_u0 V, C2[u0] = sum_u1 V and wsum(P) = sum_v v * P_v (running sums, <= 32 entries).
+hf::P1 host_wsum(const uint64_t* recs, uint32_t len) {
+    hf::P1 run = hf::p1_inf(), acc = hf::p1_inf();
+    for (uint32_t v = len; v-- > 1;) {
+        run = hf::p1_add(run, hf::p1_from_xyzz(recs + (size_t)v * kXyzzWords64));
+        acc = hf::p1_add(acc, run);
     }
-    return hf::p1_normalize(acc);
+    return acc;
+}
+hf::P1 host_shift(hf::P1 p, uint32_t k) {
+    for (uint32_t i = 0; i < k; i++) p = hf::p1_double(p);
+    return p;
+}
+hf::P1 finish_msm(const kzg_ctx* ctx, const Slot& s) {
+    const ReducePlan& P = ctx->plan;
+    const uint64_t* f = s.h_final;
+    auto at = [&](uint32_t off) { return f + (size_t)off * kXyzzWords64; };
+    // W(Row) = 2^row_lo * wsum(R2row) + wsum(C2row);  W(Col) likewise
+    hf::P1 w_row = hf::p1_add(host_shift(host_wsum(at(P.off_r2row), 1u << P.row_hi), P.row_lo),
+                              host_wsum(at(P.off_c2row), 1u << P.row_lo));
+    hf::P1 w_col = hf::p1_add(host_shift(host_wsum(at(P.off_r2col), 1u << P.col_hi), P.col_lo),
+                              host_wsum(at(P.off_c2col), 1u << P.col_lo));
+    // sum_b b B_b = C * W(Row) + W(Col);  sum_b B_b = sum of R2row
+    hf::P1 total = hf::p1_add(host_shift(w_row, P.lo_bits), w_col);
+    for (uint32_t k = 0; k < (1u << P.row_hi); k++)
+        total = hf::p1_add(total, hf::p1_from_xyzz(at(P.off_r2row + k)));
+    return hf::p1_normalize(total);
 }
 
 void write_p1(uint64_t out[18], const hf::P1& p) { std::memcpy(out, &p, sizeof p); }

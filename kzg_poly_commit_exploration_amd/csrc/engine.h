@@ -41,11 +41,9 @@ void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t
 void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t L, const void* d_part_a,
                             const void* d_part_b, void* d_buckets, uint32_t* d_heavy_list,
                             uint32_t* d_heavy_count /* pre-zeroed */);
-// one level of the weighted running-sum reduction over `n_items` XYZZ items in chunks of m:
-//   acc[k] = sum_{t<m} (t+1) * in[k*m + t],   run[k] = sum_{t<m} in[k*m + t]
-void launch_wsum_level(hipStream_t s, const void* d_in, uint32_t n_items, uint32_t m, void* d_acc, void* d_run);
-// plain chunk sums: out[k] = sum_{t<m} in[k*m + t]
-void launch_sum_level(hipStream_t s, const void* d_in, uint32_t n_items, uint32_t m, void* d_out);
+// out[g] = sum_{q<len} in[g*gstride + q*estride], XYZZ records: log-depth tree per group
+void launch_tree_sum(hipStream_t s, const void* d_in, uint32_t groups, uint32_t len, uint64_t gstride,
+                     uint64_t estride, void* d_out);
 
 // ---- srs_kernels.hip --------------------------------------------------------------------
 // blst_p1 Jacobian (host layout, strided) already copied to d_jac (n x 144 B contiguous) -> affine

@@ -1,13 +1,15 @@
 // msm_reduce.hip -- bucket reduction: sum_b (b+1) * B_b from the 2^(c-1) bucket sums.
 //
-// Level structure (host-driven, see api.hip): a level takes items I[0..n) with weights 1..n, cuts
-// them into chunks of m and lets one lane per chunk walk its chunk from the top with the classic
-// running sum (run += I; acc += run):
-//     acc[k] = sum_t (t+1) I[k m + t]        run[k] = sum_t I[k m + t]
-//     sum_i (i+1) I[i] = sum_k acc[k] + m * sum_k k run[k]
-// so the next level's items are run[1..] with weights 1.., and the acc[] arrays are plain-summed.
-// Everything here is a chain of dependent 384-bit additions at a handful of waves: it is bound by
-// the latency of the field multiplier, not by HBM or VALU throughput, and kept short (m small).
+// The weights are linear in the bucket index, so the weighted sum separates over any split of the
+// index into digits: with b = hi * C + lo,
+//        sum_b b B_b = C * sum_hi hi * Row_hi + sum_lo lo * Col_lo,
+//        Row_hi = sum_lo B[hi*C + lo],   Col_lo = sum_hi B[hi*C + lo],   sum_b B_b = sum_hi Row_hi.
+// Rows and columns are PLAIN sums -> logarithmic-depth trees instead of running-sum chains.  The same
+// split is applied once more to the Row and the Col vector (<= 1024 entries -> four vectors of <= 32
+// entries), whose short weighted sums the host finishes (api.hip).  Critical path on the device:
+// log2(C) + log2(sqrt) dependent 384-bit additions (12 at 65536 buckets) instead of ~70 with running sums;
+// the work stays 2 additions per bucket.  Everything here is bound by the latency of the field
+// multiplier (~27 us per addition for a lone wave), not by HBM or VALU throughput.
 //
 // Field products stay inlined: measured on MI355X the call-based multiplier costs the general
 // addition 40 % (2.8 vs 1.6 G additions/s, gpurun_out microbench), the register traffic around the
@@ -50,51 +52,58 @@ KZG_DEV void store_xyzz(uint4* __restrict__ out, const XYZZ& a) {
     }
 }
 
-__global__ void __launch_bounds__(64) k_wsum_level(const uint4* __restrict__ in, uint32_t n_items, uint32_t m,
-                                                   uint4* __restrict__ acc_out, uint4* __restrict__ run_out) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t chunks = (n_items + m - 1) / m;
-    if (k >= chunks) return;
-    XYZZ run = XYZZ::inf(), acc = XYZZ::inf();
-    for (uint32_t t = m; t-- > 0;) {
-        uint32_t idx = k * m + t;
-        if (idx < n_items) {
-            XYZZ b = load_xyzz(in + (size_t)idx * 12);
-            xyzz_add(run, b);
-        }
-        xyzz_add(acc, run);
-    }
-    store_xyzz(acc_out + (size_t)k * 12, acc);
-    store_xyzz(run_out + (size_t)k * 12, run);
-}
+constexpr int kTreeBlock = 256;
 
-__global__ void __launch_bounds__(64) k_sum_level(const uint4* __restrict__ in, uint32_t n_items, uint32_t m,
-                                                  uint4* __restrict__ out) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t chunks = (n_items + m - 1) / m;
-    if (k >= chunks) return;
+// out[g] = sum_{q < len} in[g * gstride + q * estride]   for g < groups  (strides in XYZZ records).
+// A workgroup of 256 lanes serves 256 / lanes_per_group groups; each lane first adds its share of the
+// group serially (only when len > 256), then the lanes of a group fold in a tree through LDS.
+__global__ void __launch_bounds__(kTreeBlock) k_tree_sum(const uint4* __restrict__ in, uint32_t groups, uint32_t len,
+                                                         uint32_t lanes_per_group /* pow2, <= 256 */, uint64_t gstride,
+                                                         uint64_t estride, uint4* __restrict__ out) {
+    __shared__ u32 lds[48 * kTreeBlock];
+    const int t = threadIdx.x;
+    const uint32_t gpb = kTreeBlock / lanes_per_group;
+    const uint32_t g = blockIdx.x * gpb + t / lanes_per_group;
+    const uint32_t l = t & (lanes_per_group - 1);
     XYZZ acc = XYZZ::inf();
-    for (uint32_t t = 0; t < m; t++) {
-        uint32_t idx = k * m + t;
-        if (idx < n_items) {
-            XYZZ b = load_xyzz(in + (size_t)idx * 12);
+    if (g < groups) {
+        for (uint32_t q = l; q < len; q += lanes_per_group) {
+            XYZZ b = load_xyzz(in + (size_t)(g * gstride + q * estride) * 12);
             xyzz_add(acc, b);
         }
     }
-    store_xyzz(out + (size_t)k * 12, acc);
+    for (uint32_t off = lanes_per_group >> 1; off >= 1; off >>= 1) {
+        __syncthreads();
+        if (l >= off && l < 2 * off) {
+            const Fp* f[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int i = 0; i < 12; i++) lds[(q * 12 + i) * kTreeBlock + (t - off)] = f[q]->l[i];
+        }
+        __syncthreads();
+        if (l < off) {
+            XYZZ o;
+            Fp* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int i = 0; i < 12; i++) f[q]->l[i] = lds[(q * 12 + i) * kTreeBlock + t];
+            xyzz_add(acc, o);
+        }
+    }
+    if (l == 0 && g < groups) store_xyzz(out + (size_t)g * 12, acc);
 }
 
-void launch_wsum_level(hipStream_t s, const void* d_in, uint32_t n_items, uint32_t m, void* d_acc, void* d_run) {
-    uint32_t chunks = (n_items + m - 1) / m;
-    if (chunks == 0) return;
-    hipLaunchKernelGGL(k_wsum_level, dim3((chunks + 63) / 64), dim3(64), 0, s, reinterpret_cast<const uint4*>(d_in),
-                       n_items, m, reinterpret_cast<uint4*>(d_acc), reinterpret_cast<uint4*>(d_run));
-}
-void launch_sum_level(hipStream_t s, const void* d_in, uint32_t n_items, uint32_t m, void* d_out) {
-    uint32_t chunks = (n_items + m - 1) / m;
-    if (chunks == 0) return;
-    hipLaunchKernelGGL(k_sum_level, dim3((chunks + 63) / 64), dim3(64), 0, s, reinterpret_cast<const uint4*>(d_in),
-                       n_items, m, reinterpret_cast<uint4*>(d_out));
+void launch_tree_sum(hipStream_t s, const void* d_in, uint32_t groups, uint32_t len, uint64_t gstride, uint64_t estride,
+                     void* d_out) {
+    if (!groups) return;
+    uint32_t lpg = 1;
+    while (lpg < len && lpg < (uint32_t)kTreeBlock) lpg <<= 1;
+    uint32_t gpb = kTreeBlock / lpg;
+    hipLaunchKernelGGL(k_tree_sum, dim3((groups + gpb - 1) / gpb), dim3(kTreeBlock), 0, s,
+                       reinterpret_cast<const uint4*>(d_in), groups, len, lpg, gstride, estride,
+                       reinterpret_cast<uint4*>(d_out));
 }
 
 }  // namespace kzg
