@@ -26,7 +26,7 @@ namespace hf = kzg_host;
 
 namespace {
 
-constexpr int kNumSlots = 3;
+constexpr int kNumSlots = 4;
 // Reduction plan (msm_reduce.hip): bucket index b = hi * C + lo; Row (R entries) and Col (C entries)
 // are each split once more into a "row" part and a "column" part that the host receives.
 struct ReducePlan {
@@ -244,13 +244,17 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         char* row = (char*)s.d_arena;
         char* col = row + (size_t)R * kXyzzBytes;
         char* fin = (char*)s.d_final;
-        launch_tree_sum(st, s.d_buckets, R, C, C, 1, row);  // Row[hi] = sum_lo B[hi*C + lo]
-        launch_tree_sum(st, s.d_buckets, C, R, 1, C, col);  // Col[lo] = sum_hi B[hi*C + lo]
         const uint32_t rl = 1u << P.row_lo, rh = 1u << P.row_hi, cl = 1u << P.col_lo, ch = 1u << P.col_hi;
-        launch_tree_sum(st, row, rh, rl, rl, 1, fin + (size_t)P.off_r2row * kXyzzBytes);
-        launch_tree_sum(st, row, rl, rh, 1, rl, fin + (size_t)P.off_c2row * kXyzzBytes);
-        launch_tree_sum(st, col, ch, cl, cl, 1, fin + (size_t)P.off_r2col * kXyzzBytes);
-        launch_tree_sum(st, col, cl, ch, 1, cl, fin + (size_t)P.off_c2col * kXyzzBytes);
+        TreeSumDesc stage1[2] = {
+            {s.d_buckets, row, R, C, C, 1},   // Row[hi] = sum_lo B[hi*C + lo]
+            {s.d_buckets, col, C, R, 1, C}};  // Col[lo] = sum_hi B[hi*C + lo]
+        launch_tree_sums(st, stage1, 2);
+        TreeSumDesc stage2[4] = {
+            {row, fin + (size_t)P.off_r2row * kXyzzBytes, rh, rl, rl, 1},
+            {row, fin + (size_t)P.off_c2row * kXyzzBytes, rl, rh, 1, rl},
+            {col, fin + (size_t)P.off_r2col * kXyzzBytes, ch, cl, cl, 1},
+            {col, fin + (size_t)P.off_c2col * kXyzzBytes, cl, ch, 1, cl}};
+        launch_tree_sums(st, stage2, 4);
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 5], st));
     HIP_TRY(ctx, hipMemcpyAsync(s.h_final, s.d_final, ctx->final_records * kXyzzBytes, hipMemcpyDeviceToHost, st));

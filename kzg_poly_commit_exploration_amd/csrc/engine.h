@@ -41,9 +41,15 @@ void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t
 void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t L, const void* d_part_a,
                             const void* d_part_b, void* d_buckets, uint32_t* d_heavy_list,
                             uint32_t* d_heavy_count /* pre-zeroed */);
-// out[g] = sum_{q<len} in[g*gstride + q*estride], XYZZ records: log-depth tree per group
-void launch_tree_sum(hipStream_t s, const void* d_in, uint32_t groups, uint32_t len, uint64_t gstride,
-                     uint64_t estride, void* d_out);
+// out[g] = sum_{q<len} in[g*gstride + q*estride], XYZZ records: log-depth tree per group;
+// up to four independent jobs per launch
+struct TreeSumDesc {
+    const void* in;
+    void* out;
+    uint32_t groups, len;
+    uint64_t gstride, estride;
+};
+void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count);
 
 // ---- srs_kernels.hip --------------------------------------------------------------------
 // blst_p1 Jacobian (host layout, strided) already copied to d_jac (n x 144 B contiguous) -> affine

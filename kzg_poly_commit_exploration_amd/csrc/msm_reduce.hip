@@ -57,18 +57,34 @@ constexpr int kTreeBlock = 256;
 // out[g] = sum_{q < len} in[g * gstride + q * estride]   for g < groups  (strides in XYZZ records).
 // A workgroup of 256 lanes serves 256 / lanes_per_group groups; each lane first adds its share of the
 // group serially (only when len > 256), then the lanes of a group fold in a tree through LDS.
-__global__ void __launch_bounds__(kTreeBlock) k_tree_sum(const uint4* __restrict__ in, uint32_t groups, uint32_t len,
-                                                         uint32_t lanes_per_group /* pow2, <= 256 */, uint64_t gstride,
-                                                         uint64_t estride, uint4* __restrict__ out) {
+// Up to four independent jobs share one launch (their dependent-addition chains run side by side).
+struct TreeJob {
+    const uint4* in;
+    uint4* out;
+    uint32_t groups, len, lanes_per_group, first_block;
+    uint64_t gstride, estride;
+};
+struct TreeJobs {
+    TreeJob j[4];
+    uint32_t count;
+};
+
+__global__ void __launch_bounds__(kTreeBlock) k_tree_sum(TreeJobs jobs) {
     __shared__ u32 lds[48 * kTreeBlock];
     const int t = threadIdx.x;
+    uint32_t ji = 0;
+#pragma unroll
+    for (uint32_t q = 1; q < 4; q++)
+        if (q < jobs.count && blockIdx.x >= jobs.j[q].first_block) ji = q;
+    const TreeJob J = jobs.j[ji];
+    const uint32_t lanes_per_group = J.lanes_per_group;
     const uint32_t gpb = kTreeBlock / lanes_per_group;
-    const uint32_t g = blockIdx.x * gpb + t / lanes_per_group;
+    const uint32_t g = (blockIdx.x - J.first_block) * gpb + t / lanes_per_group;
     const uint32_t l = t & (lanes_per_group - 1);
     XYZZ acc = XYZZ::inf();
-    if (g < groups) {
-        for (uint32_t q = l; q < len; q += lanes_per_group) {
-            XYZZ b = load_xyzz(in + (size_t)(g * gstride + q * estride) * 12);
+    if (g < J.groups) {
+        for (uint32_t q = l; q < J.len; q += lanes_per_group) {
+            XYZZ b = load_xyzz(J.in + (size_t)(g * J.gstride + q * J.estride) * 12);
             xyzz_add(acc, b);
         }
     }
@@ -92,18 +108,29 @@ __global__ void __launch_bounds__(kTreeBlock) k_tree_sum(const uint4* __restrict
             xyzz_add(acc, o);
         }
     }
-    if (l == 0 && g < groups) store_xyzz(out + (size_t)g * 12, acc);
+    if (l == 0 && g < J.groups) store_xyzz(J.out + (size_t)g * 12, acc);
 }
 
-void launch_tree_sum(hipStream_t s, const void* d_in, uint32_t groups, uint32_t len, uint64_t gstride, uint64_t estride,
-                     void* d_out) {
-    if (!groups) return;
-    uint32_t lpg = 1;
-    while (lpg < len && lpg < (uint32_t)kTreeBlock) lpg <<= 1;
-    uint32_t gpb = kTreeBlock / lpg;
-    hipLaunchKernelGGL(k_tree_sum, dim3((groups + gpb - 1) / gpb), dim3(kTreeBlock), 0, s,
-                       reinterpret_cast<const uint4*>(d_in), groups, len, lpg, gstride, estride,
-                       reinterpret_cast<uint4*>(d_out));
+void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count) {
+    TreeJobs jobs;
+    jobs.count = count;
+    uint32_t blocks = 0;
+    for (uint32_t i = 0; i < count && i < 4; i++) {
+        uint32_t lpg = 1;
+        while (lpg < descs[i].len && lpg < (uint32_t)kTreeBlock) lpg <<= 1;
+        uint32_t gpb = kTreeBlock / lpg;
+        jobs.j[i].in = reinterpret_cast<const uint4*>(descs[i].in);
+        jobs.j[i].out = reinterpret_cast<uint4*>(descs[i].out);
+        jobs.j[i].groups = descs[i].groups;
+        jobs.j[i].len = descs[i].len;
+        jobs.j[i].lanes_per_group = lpg;
+        jobs.j[i].first_block = blocks;
+        jobs.j[i].gstride = descs[i].gstride;
+        jobs.j[i].estride = descs[i].estride;
+        blocks += (descs[i].groups + gpb - 1) / gpb;
+    }
+    if (!blocks) return;
+    hipLaunchKernelGGL(k_tree_sum, dim3(blocks), dim3(kTreeBlock), 0, s, jobs);
 }
 
 }  // namespace kzg
