@@ -82,8 +82,8 @@ def cpu_baseline(eng, coeff_limbs, sample):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--degree", type=int, default=DEGREE)
     ap.add_argument("--cpu-sample", type=int, default=1 << 15)
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -145,9 +145,9 @@ int kzg_g1_compress(const uint64_t p1[18], uint8_t out[48]);
 typedef struct kzg_kernel_times {
     /* per-kernel HIP-event times of the most recent kzg_wait on the slot, milliseconds, measured on
      * the stream the kernels ran on (only filled while timing is enabled) */
-    float digits_ms;      /* scalar recoding + bucket histogram */
-    float scan_ms;        /* bucket offsets (+ bucket ordering) */
-    float scatter_ms;     /* counting-sort scatter of (point, sign) references */
+    float digits_ms;      /* scalar recoding + two-level counting sort (all of msm_sort.hip) */
+    float scan_ms;        /* unused (kept for layout stability) */
+    float scatter_ms;     /* buffer clears + wait for the shared accumulation stream */
     float accumulate_ms;  /* bucket accumulation: the dominant kernel */
     float reduce_ms;      /* bucket running-sum reduction levels */
     float quotient_ms;    /* open only: scalar-field synthetic division */

@@ -36,7 +36,7 @@ constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on ceil(max_refs / ac
 uint32_t accumulate_segment_len(uint64_t max_refs);
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
                               uint32_t nb, uint32_t L, uint64_t max_refs, void* d_buckets /* pre-zeroed */,
-                              void* d_part_a, void* d_part_b);
+                              void* d_part_a, void* d_part_b, uint32_t lds_reserve_bytes);
 // adds the head / tail partials of buckets that span several segments (serial, or tree for long spans)
 void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t L, const void* d_part_a,
                             const void* d_part_b, void* d_buckets, uint32_t* d_heavy_list,

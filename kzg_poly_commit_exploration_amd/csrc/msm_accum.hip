@@ -206,11 +206,11 @@ uint32_t accumulate_segment_len(uint64_t max_refs) {
 
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
                               uint32_t nb, uint32_t L, uint64_t max_refs, void* d_buckets, void* d_part_a,
-                              void* d_part_b) {
+                              void* d_part_b, uint32_t lds_reserve_bytes) {
     uint32_t lanes = (uint32_t)((max_refs + L - 1) / L);
     if (!lanes) return;
-    hipLaunchKernelGGL(k_bucket_accumulate, dim3((lanes + kAccumBlock - 1) / kAccumBlock), dim3(kAccumBlock), 0, s,
-                       reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb, L,
+    hipLaunchKernelGGL(k_bucket_accumulate, dim3((lanes + kAccumBlock - 1) / kAccumBlock), dim3(kAccumBlock),
+                       lds_reserve_bytes, s, reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb, L,
                        reinterpret_cast<uint4*>(d_buckets), reinterpret_cast<uint4*>(d_part_a),
                        reinterpret_cast<uint4*>(d_part_b));
 }
