@@ -66,8 +66,8 @@ const char* kzg_last_error(const kzg_ctx* ctx);
  * reference src/trusted_setup.rs:31-35; the shim passes &srs[0].g1 so no field offset is
  * assumed).  Points are Jacobian with arbitrary Z as blst_p1_mult leaves them
  * (src/trusted_setup.rs:54-62); the library normalises them to affine on the device and builds
- * its window tables.  `index_base` is the global index of first_g1 in the full SRS (0 for a
- * single GPU; rank g of a sharded MSM passes its slice start and commits slice-relative). */
+ * its window tables.  A rank of a sharded MSM loads only its slice of the SRS and commits the
+ * matching coefficient slice (indices are slice-relative). */
 int kzg_srs_load_g1(kzg_ctx* ctx, const void* first_g1, size_t stride_bytes, size_t n);
 
 /* Trusted setup on the device, G1 side only: SRS[i] = [s^i mod r]G1 for i in [first, first+n),
