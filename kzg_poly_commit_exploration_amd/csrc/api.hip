@@ -26,7 +26,7 @@ namespace hf = kzg_host;
 
 namespace {
 
-constexpr int kNumSlots = 4;
+constexpr int kNumSlots = 3;  // + the shared accumulation stream = the 4 hardware queues HIP gives a process by default
 // Reduction plan (msm_reduce.hip): bucket index b = hi * C + lo; Row (R entries) and Col (C entries)
 // are each split once more into a "row" part and a "column" part that the host receives.
 struct ReducePlan {
@@ -90,10 +90,10 @@ struct kzg_ctx {
     // the light sort / reduction kernels of the other slots run beside it on the slots' own streams.
     hipStream_t heavy_stream = nullptr;
     bool serialize_accum = true;   // KZG_SERIALIZE_ACCUM=0 lets accumulation kernels of different slots overlap
-    // LDS reserved per accumulation workgroup (KZG_ACCUM_LDS_KB overrides): 54 KB keeps the kernel at two
-    // workgroups per CU (2 waves/SIMD, 252 of 512 VGPRs) so that the sort / finalise / tree kernels of the
-    // other slots find registers and run beside it; measured +3 % commitments/s over no reservation.
-    uint32_t accum_lds_bytes = 54u * 1024u;
+    // LDS reserved per accumulation workgroup (KZG_ACCUM_LDS_KB, default none): occupancy-shaping knob for
+    // experiments.  54 KB (2 waves/SIMD) lets the reduction kernels of other slots run beside the
+    // accumulation but slows it by 5 %; with 8 slots in flight the full-occupancy kernel wins.
+    uint32_t accum_lds_bytes = 0;
     bool slots_ready = false;
     bool timing = false;
 };

@@ -12,15 +12,14 @@
 // Roofline: VALU (integer multiply) bound.  Per reference ~2900 v_mad_u64_u32 + ~6000 other VALU ops
 // against 96 B gathered from the table + 4 B of reference.  Algorithmic HBM bytes per commitment are
 // those of SURVEY.md section 8(d): 128 B x n + 144 B.
+#include <cstdlib>
+
 #include "engine.h"
 #include "g1.hip.h"
 
 namespace kzg {
 
 constexpr int kAccumBlock = 256;
-constexpr uint32_t kSerialSpan = 48;  // buckets spanning more segments than this go to the tree kernel
-constexpr int kHeavyBlock = 256;
-constexpr int kHeavyGrid = 512;
 
 KZG_DEV Affine load_affine(const uint4* __restrict__ table, uint32_t idx) {
     const uint4* p = table + (size_t)idx * 6;
@@ -50,7 +49,7 @@ KZG_DEV void store_xyzz(uint4* __restrict__ out, const XYZZ& a) {
         }
     }
 }
-KZG_DEV XYZZ load_xyzz(const uint4* __restrict__ in) {
+[[maybe_unused]] KZG_DEV XYZZ load_xyzz(const uint4* __restrict__ in) {
     XYZZ a;
     Fp* f[4] = {&a.X, &a.Y, &a.ZZ, &a.ZZZ};
 #pragma unroll
@@ -81,7 +80,7 @@ KZG_DEV uint32_t bucket_of(const uint32_t* __restrict__ offs, uint32_t nb, uint3
 //   complete runs   -> buckets[b]
 //   run touching the segment start (bucket continues from the previous lane, or the whole segment
 //   lies inside one bucket) -> part_a[lane];  run touching only the segment end -> part_b[lane]
-__global__ void __launch_bounds__(kAccumBlock) k_bucket_accumulate(const uint4* __restrict__ table,
+__global__ void __launch_bounds__(kAccumBlock, 4) k_bucket_accumulate(const uint4* __restrict__ table,
                                                                   const uint32_t* __restrict__ sorted,
                                                                   const uint32_t* __restrict__ offs, uint32_t nb,
                                                                   uint32_t L, uint4* __restrict__ buckets,
@@ -123,83 +122,15 @@ __global__ void __launch_bounds__(kAccumBlock) k_bucket_accumulate(const uint4* 
     store_xyzz(dst, acc);
 }
 
-// Buckets that span several segments: add up their partials (first segment's tail or whole, whole
-// middle segments, last segment's head).  One lane per bucket; very long spans (skewed scalars) are
-// queued for k_bucket_heavy.
-__global__ void __launch_bounds__(64) k_bucket_finalize(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t L,
-                                                        const uint4* __restrict__ part_a,
-                                                        const uint4* __restrict__ part_b,
-                                                        uint4* __restrict__ buckets,
-                                                        uint32_t* __restrict__ heavy_list,
-                                                        uint32_t* __restrict__ heavy_count) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    uint32_t s = offs[b], e = offs[b + 1];
-    if (s == e) return;  // empty bucket: stays at infinity (buffer pre-zeroed)
-    uint32_t l_lo = s / L, l_hi = (e - 1) / L;
-    if (l_lo == l_hi) return;  // inside one segment: written complete by k_bucket_accumulate
-    if (l_hi - l_lo + 1 > kSerialSpan) {
-        uint32_t slot = atomicAdd(heavy_count, 1u);
-        heavy_list[slot] = b;
-        return;
-    }
-    const uint4* first = (s == l_lo * L) ? part_a + (size_t)l_lo * 12 : part_b + (size_t)l_lo * 12;
-    XYZZ acc = load_xyzz(first);
-    for (uint32_t l = l_lo + 1; l <= l_hi; l++) {
-        XYZZ p = load_xyzz(part_a + (size_t)l * 12);
-        xyzz_add(acc, p);
-    }
-    store_xyzz(buckets + (size_t)b * 12, acc);
-}
-
-// One workgroup per queued bucket: strided partial sums, then a tree in LDS.
-__global__ void __launch_bounds__(kHeavyBlock) k_bucket_heavy(const uint32_t* __restrict__ offs, uint32_t L,
-                                                              const uint4* __restrict__ part_a,
-                                                              const uint4* __restrict__ part_b,
-                                                              uint4* __restrict__ buckets,
-                                                              const uint32_t* __restrict__ heavy_list,
-                                                              const uint32_t* __restrict__ heavy_count) {
-    __shared__ u32 lds[48 * kHeavyBlock];
-    const int t = threadIdx.x;
-    const uint32_t count = *heavy_count;
-    for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
-        uint32_t b = heavy_list[h];
-        uint32_t s = offs[b], e = offs[b + 1];
-        uint32_t l_lo = s / L, l_hi = (e - 1) / L;
-        XYZZ acc = XYZZ::inf();
-        for (uint32_t l = l_lo + t; l <= l_hi; l += kHeavyBlock) {
-            const uint4* src = (l == l_lo && s != l_lo * L) ? part_b + (size_t)l * 12 : part_a + (size_t)l * 12;
-            XYZZ p = load_xyzz(src);
-            xyzz_add(acc, p);
-        }
-        for (int off = kHeavyBlock / 2; off >= 1; off >>= 1) {
-            __syncthreads();
-            if (t >= off && t < 2 * off) {
-                const Fp* f[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-#pragma unroll
-                    for (int i = 0; i < 12; i++) lds[(q * 12 + i) * kHeavyBlock + (t - off)] = f[q]->l[i];
-            }
-            __syncthreads();
-            if (t < off) {
-                XYZZ o;
-                Fp* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-#pragma unroll
-                    for (int i = 0; i < 12; i++) f[q]->l[i] = lds[(q * 12 + i) * kHeavyBlock + t];
-                xyzz_add(acc, o);
-            }
-        }
-        if (t == 0) store_xyzz(buckets + (size_t)b * 12, acc);
-        __syncthreads();
-    }
-}
-
 uint32_t accumulate_segment_len(uint64_t max_refs) {
-    // about one segment per resident lane of the chip (256 CUs x 4 SIMDs x 4 waves x 64 lanes)
-    uint64_t L = (max_refs + 262143) / 262144;
+    // one segment per resident lane of the chip (256 CUs x 4 SIMDs x 4 waves x 64 lanes): the whole grid
+    // is resident at once, a second partially filled round of workgroups would cost up to 2x.
+    static const uint64_t lanes = [] {
+        const char* v = std::getenv("KZG_ACCUM_LANES");
+        uint64_t l = v ? std::strtoull(v, nullptr, 10) : 262144ull;
+        return l < 64 ? 262144ull : (l > 262144ull ? 262144ull : l);
+    }();
+    uint64_t L = (max_refs + lanes - 1) / lanes;
     if (L < 8) L = 8;
     return (uint32_t)L;
 }
@@ -213,16 +144,6 @@ void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t
                        lds_reserve_bytes, s, reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb, L,
                        reinterpret_cast<uint4*>(d_buckets), reinterpret_cast<uint4*>(d_part_a),
                        reinterpret_cast<uint4*>(d_part_b));
-}
-
-void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t L, const void* d_part_a,
-                            const void* d_part_b, void* d_buckets, uint32_t* d_heavy_list, uint32_t* d_heavy_count) {
-    hipLaunchKernelGGL(k_bucket_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, d_offs, nb, L,
-                       reinterpret_cast<const uint4*>(d_part_a), reinterpret_cast<const uint4*>(d_part_b),
-                       reinterpret_cast<uint4*>(d_buckets), d_heavy_list, d_heavy_count);
-    hipLaunchKernelGGL(k_bucket_heavy, dim3(kHeavyGrid), dim3(kHeavyBlock), 0, s, d_offs, L,
-                       reinterpret_cast<const uint4*>(d_part_a), reinterpret_cast<const uint4*>(d_part_b),
-                       reinterpret_cast<uint4*>(d_buckets), d_heavy_list, d_heavy_count);
 }
 
 }  // namespace kzg

@@ -98,7 +98,7 @@ KZG_DEV void for_each_digit(u32 k[8], uint32_t c, uint32_t W, F&& f) {
 //           references are moved to their final, bucket-major position
 // No global atomics, no rank array; order inside a bucket is arbitrary (the group law is commutative,
 // the result is bit-identical).
-constexpr int kSortBlock = 1024;
+constexpr int kSortBlock = 256;
 constexpr int kMaxCoarse = 2048;
 constexpr int kFineMax = 256;
 
