@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1 << 15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slots", type=int, default=0, help="stream slots kept in flight (0 = all the engine has)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (RCCL) even at world size 1: exercises the exchange path on one GPU")
     args = ap.parse_args()
 
     import numpy as np
@@ -107,10 +109,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     def barrier():
@@ -147,7 +150,7 @@ def main():
         accum_ms.append(t["accumulate_ms"])
         for k, v in t.items():
             phase_ms.setdefault(k, []).append(v)
-        if world > 1:
+        if dist is not None:
             partial = combine(allgather_partials(partial, device=dev))
         results.append(partial)
 

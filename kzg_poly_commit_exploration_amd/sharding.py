@@ -19,19 +19,49 @@ def shard_range(n, rank, world):
     return lo, min(n, lo + per)
 
 
+_BUFFERS = {}
+
+
+def _buffers(world, device):
+    """Persistent staging buffers: pinned host in/out plus device in/out (18 x int64 per rank)."""
+    import torch
+
+    key = (world, str(device))
+    if key not in _BUFFERS:
+        pin = device is not None
+        h_in = torch.empty(18, dtype=torch.int64, pin_memory=pin)
+        h_out = torch.empty(18 * world, dtype=torch.int64, pin_memory=pin)
+        if device is not None:
+            d_in = torch.empty(18, dtype=torch.int64, device=device)
+            d_out = torch.empty(18 * world, dtype=torch.int64, device=device)
+        else:
+            d_in, d_out = h_in, h_out
+        _BUFFERS[key] = (h_in, h_out, d_in, d_out)
+    return _BUFFERS[key]
+
+
 def allgather_partials(partial, device=None, group=None):
-    """All-gathers one G1Point per rank through torch.distributed and returns them in rank order."""
+    """All-gathers one G1Point (144 B) per rank through torch.distributed, rank order preserved.
+
+    With `device` set the exchange runs on the GPU (backend nccl = RCCL over xGMI): one tiny H2D copy,
+    one all_gather_into_tensor, one D2H copy, all on persistent buffers.  uint64 limbs travel as int64."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    # uint64 limbs travel as int64 (same bits); RCCL needs device tensors, gloo takes CPU ones
-    mine = torch.from_numpy(partial.p1.view(np.int64).copy())
+    h_in, h_out, d_in, d_out = _buffers(world, device)
+    h_in.numpy()[:] = partial.p1.view(np.int64)
     if device is not None:
-        mine = mine.to(device)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    return [G1Point(t.cpu().numpy().view(np.uint64)) for t in gathered]
+        d_in.copy_(h_in, non_blocking=True)
+        dist.all_gather_into_tensor(d_out, d_in, group=group)
+        h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+    else:
+        gathered = [torch.empty_like(h_in) for _ in range(world)]
+        dist.all_gather(gathered, h_in, group=group)
+        h_out.copy_(torch.cat(gathered))
+    arr = h_out.numpy().view(np.uint64).reshape(world, 18)
+    return [G1Point(arr[r].copy()) for r in range(world)]
 
 
 def combine(partials):

@@ -349,6 +349,23 @@ def test_degree_2_20_commit_and_proof_golden(engines, oracle, golden):
     assert rc == 0 and np.array_equal(q, q_want)
 
 
+# ---------------------------------------------------------------- 2^22 (BASELINE config 4 size, one GPU)
+
+def test_degree_2_22_commit_and_proof_golden(oracle, golden):
+    d = 1 << 22
+    secret = bytes.fromhex(golden["secret_be"])
+    eng = K.SetupArtifactsGenerator(secret).take(d + 1)
+    try:
+        assert oracle.p1_compress(eng.srs_read(d, 1)[0]).hex() == golden["srs_g1"][str(d)]
+        c, z, y = _bench_poly(oracle, d)
+        case = _case(golden, d)
+        assert "%x" % y.v == case["y"]
+        assert eng.commit_limbs(c).compress().hex() == case["commit"]
+        assert eng.open_limbs(c, z, y).compress().hex() == case["proof"]
+    finally:
+        eng.close()
+
+
 # ---------------------------------------------------------------- C++ host mirror over the same C-ABI
 
 def test_cpp_mirror_example(twin):
