@@ -123,6 +123,17 @@ int kzg_open_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, cons
                     const uint64_t y[4]);
 int kzg_wait(kzg_ctx* ctx, int slot, uint64_t out_p1[18]);
 
+/* Batches: `batch` polynomials of n coefficients each (polynomial p at d_coeffs + p * stride_coeffs
+ * blst_fr values), committed against the same SRS in ONE pass of the kernels -- the shape of
+ * BASELINE config 5 and what keeps small per-GPU shards efficient when a commitment is sharded over
+ * several GPUs.  kzg_set_max_batch sizes the workspaces (default 1; it is clamped to what the sort's
+ * bin table allows, read it back with kzg_max_batch).  n <= kzg_srs_len. */
+int kzg_set_max_batch(kzg_ctx* ctx, size_t max_batch);
+size_t kzg_max_batch(const kzg_ctx* ctx);
+int kzg_commit_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch,
+                            size_t stride_coeffs);
+int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s /* batch x 18 */, size_t batch);
+
 /* raw device memory helpers so a non-HIP host (Rust, Python) can stage device-resident inputs */
 int kzg_dev_alloc(kzg_ctx* ctx, size_t bytes, void** out_dptr);
 int kzg_dev_free(kzg_ctx* ctx, void* dptr);

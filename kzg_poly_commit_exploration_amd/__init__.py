@@ -41,6 +41,7 @@ ABI_SYMBOLS = [
     "kzg_srs_load_g1", "kzg_srs_generate_g1", "kzg_srs_read_g1", "kzg_srs_len",
     "kzg_commit", "kzg_commit_le_bytes", "kzg_open", "kzg_quotient", "kzg_evaluate",
     "kzg_num_slots", "kzg_commit_submit", "kzg_open_submit", "kzg_wait",
+    "kzg_set_max_batch", "kzg_max_batch", "kzg_commit_batch_submit", "kzg_wait_batch",
     "kzg_dev_alloc", "kzg_dev_free", "kzg_dev_upload", "kzg_dev_download",
     "kzg_g1_sum", "kzg_g1_compress", "kzg_set_timing", "kzg_get_times", "kzg_msm_config",
 ]
@@ -96,6 +97,10 @@ def load_library():
         "kzg_commit_submit": (i, [vp, i, vp, sz]),
         "kzg_open_submit": (i, [vp, i, vp, sz, vp, vp]),
         "kzg_wait": (i, [vp, i, vp]),
+        "kzg_set_max_batch": (i, [vp, sz]),
+        "kzg_max_batch": (sz, [vp]),
+        "kzg_commit_batch_submit": (i, [vp, i, vp, sz, sz, sz]),
+        "kzg_wait_batch": (i, [vp, i, vp, sz]),
         "kzg_dev_alloc": (i, [vp, sz, C.POINTER(vp)]),
         "kzg_dev_free": (i, [vp, vp]),
         "kzg_dev_upload": (i, [vp, vp, vp, sz]),
@@ -366,6 +371,36 @@ class Engine:
         out = np.zeros(18, dtype=np.uint64)
         _check(self._lib.kzg_wait(self._h, slot, _ptr(out)), self._h)
         return G1Point(out)
+
+    def set_max_batch(self, b):
+        _check(self._lib.kzg_set_max_batch(self._h, b), self._h)
+        return int(self._lib.kzg_max_batch(self._h))
+
+    def max_batch(self):
+        return int(self._lib.kzg_max_batch(self._h))
+
+    def commit_batch_submit(self, slot, dptr, n, batch, stride=None):
+        _check(self._lib.kzg_commit_batch_submit(self._h, slot, C.c_void_p(dptr), n, batch, n if stride is None else stride),
+               self._h)
+
+    def wait_batch(self, slot, batch):
+        out = np.zeros((batch, 18), dtype=np.uint64)
+        _check(self._lib.kzg_wait_batch(self._h, slot, _ptr(out), batch), self._h)
+        return [G1Point(out[i]) for i in range(batch)]
+
+    def commit_batch_limbs(self, polys):
+        """Commits several coefficient arrays (each (n, 4) uint64, same n) in one batched pass."""
+        polys = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in polys]
+        n = polys[0].shape[0]
+        assert all(p.shape[0] == n for p in polys)
+        flat = np.concatenate(polys)
+        dptr = self.dev_alloc(flat.nbytes)
+        try:
+            self.dev_upload(dptr, flat)
+            self.commit_batch_submit(0, dptr, n, len(polys))
+            return self.wait_batch(0, len(polys))
+        finally:
+            self.dev_free(dptr)
 
     # -- measurement --
     def set_timing(self, enabled):

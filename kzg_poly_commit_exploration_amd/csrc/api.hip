@@ -65,6 +65,7 @@ struct Slot {
     // state of the job in flight
     SlotKind kind = SLOT_IDLE;
     size_t job_n = 0;
+    uint32_t job_batch = 1;
     uint32_t open_y[8] = {};
     bool timing = false;
     bool has_quotient = false;
@@ -83,7 +84,8 @@ struct kzg_ctx {
     MsmConfig cfg = {};
     void* d_table = nullptr;  // W * n affine points
     ReducePlan plan;
-    size_t arena_records = 0, final_records = 0;
+    size_t arena_records = 0, final_records = 0;  // per polynomial of a batch
+    uint32_t max_batch = 1;                        // polynomials per submit the workspaces are sized for
     Slot slots[kNumSlots];
     // All bucket-accumulation kernels run on ONE stream, in submission order: each fills the chip on its
     // own, so letting two of them overlap only makes both slower (and their timings meaningless), while
@@ -162,7 +164,9 @@ int setup_slots(kzg_ctx* ctx) {
     plan_reduce(ctx);
     if (!ctx->heavy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->heavy_stream, hipStreamNonBlocking));
     const MsmConfig cfg = ctx->cfg;
-    const size_t pairs = (size_t)cfg.W * ctx->n;
+    if (ctx->max_batch > sort_max_batch(cfg)) ctx->max_batch = sort_max_batch(cfg);
+    const size_t B = ctx->max_batch;
+    const size_t pairs = (size_t)cfg.W * ctx->n * B;
     for (int i = 0; i < kNumSlots; i++) {
         Slot& s = ctx->slots[i];
         if (!s.stream) {
@@ -177,18 +181,18 @@ int setup_slots(kzg_ctx* ctx) {
             HIP_TRY(ctx, hipEventCreateWithFlags(&s.accum_ev, hipEventDisableTiming));
         }
         free_slot_msm(s);
-        HIP_TRY(ctx, hipMalloc(&s.d_cnt, (size_t)sort_count_entries((uint32_t)ctx->n, cfg) * 4 + 64));
-        HIP_TRY(ctx, hipMalloc(&s.d_offs, ((size_t)cfg.nb + 1) * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_cnt, (size_t)sort_count_entries((uint32_t)B, cfg) * 4 + 64));
+        HIP_TRY(ctx, hipMalloc(&s.d_offs, ((size_t)cfg.nb * B + 1) * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_block_sums, 1024 * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_pairs, (pairs ? pairs : 1) * 8));
         HIP_TRY(ctx, hipMalloc(&s.d_sorted, (pairs ? pairs : 1) * 4));
-        HIP_TRY(ctx, hipMalloc(&s.d_buckets, (size_t)cfg.nb * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_buckets, (size_t)cfg.nb * B * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_part_a, (size_t)kMaxAccumLanes * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_part_b, (size_t)kMaxAccumLanes * kXyzzBytes));
-        HIP_TRY(ctx, hipMalloc(&s.d_heavy_list, (size_t)cfg.nb * 4));
-        HIP_TRY(ctx, hipMalloc(&s.d_arena, ctx->arena_records * kXyzzBytes));
-        HIP_TRY(ctx, hipMalloc(&s.d_final, ctx->final_records * kXyzzBytes));
-        HIP_TRY(ctx, hipHostMalloc(&s.h_final, ctx->final_records * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_heavy_list, (size_t)cfg.nb * B * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_arena, ctx->arena_records * B * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_final, ctx->final_records * B * kXyzzBytes));
+        HIP_TRY(ctx, hipHostMalloc(&s.h_final, ctx->final_records * B * kXyzzBytes));
         s.kind = SLOT_IDLE;
     }
     ctx->slots_ready = true;
@@ -232,20 +236,22 @@ int srs_prepare(kzg_ctx* ctx, size_t n) {
     return KZG_OK;
 }
 
-// enqueue the MSM over n scalars at d_scalars on slot s
-int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, size_t n, int ev_base) {
+// enqueue `batch` MSMs of n scalars each (polynomial p at d_scalars + p * stride scalars) on slot s
+int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, size_t n, int ev_base,
+                uint32_t batch = 1, uint64_t stride = 0) {
     const MsmConfig cfg = ctx->cfg;
+    const uint32_t nbt = cfg.nb * batch;  // polynomial-major bucket ids
     hipStream_t st = s.stream;
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base], st));
-    launch_bucket_sort(st, d_scalars, is_mont, (uint32_t)n, (uint32_t)ctx->n, cfg, s.d_cnt, s.d_block_sums, s.d_pairs,
-                       s.d_offs, s.d_sorted);
+    launch_bucket_sort(st, d_scalars, is_mont, (uint32_t)n, batch, stride, (uint32_t)ctx->n, cfg, s.d_cnt,
+                       s.d_block_sums, s.d_pairs, s.d_offs, s.d_sorted);
     if (s.timing) {
         HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 1], st));
         HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 2], st));
     }
-    const uint64_t max_refs = (uint64_t)n * cfg.W;
+    const uint64_t max_refs = (uint64_t)n * cfg.W * batch;
     const uint32_t L = accumulate_segment_len(max_refs);
-    HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)cfg.nb * kXyzzBytes, st));  // zero = infinity
+    HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)nbt * kXyzzBytes, st));  // zero = infinity
     HIP_TRY(ctx, hipMemsetAsync(s.d_small + 25, 0, 4, st));
     // hand over to the shared accumulation stream and back
     hipStream_t hs = ctx->serialize_accum ? ctx->heavy_stream : st;
@@ -254,36 +260,37 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         HIP_TRY(ctx, hipStreamWaitEvent(hs, s.sorted_ev, 0));
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 3], hs));
-    launch_bucket_accumulate(hs, ctx->d_table, s.d_sorted, s.d_offs, cfg.nb, L, max_refs, s.d_buckets, s.d_part_a,
+    launch_bucket_accumulate(hs, ctx->d_table, s.d_sorted, s.d_offs, nbt, L, max_refs, s.d_buckets, s.d_part_a,
                              s.d_part_b, ctx->accum_lds_bytes);
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], hs));
     if (ctx->serialize_accum) {
         HIP_TRY(ctx, hipEventRecord(s.accum_ev, hs));
         HIP_TRY(ctx, hipStreamWaitEvent(st, s.accum_ev, 0));
     }
-    launch_bucket_finalize(st, s.d_offs, cfg.nb, L, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_list,
-                           s.d_small + 25);
-    // reduction: Row / Col tree sums of the bucket matrix, each split once more
+    launch_bucket_finalize(st, s.d_offs, nbt, L, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_list, s.d_small + 25);
+    // reduction: Row / Col tree sums of every polynomial's bucket matrix, each split once more.
+    // Vectors are polynomial-major ([p][index]); the final buffer holds four sections [p][len_k].
     {
         const ReducePlan& P = ctx->plan;
-        const uint32_t R = 1u << P.hi_bits, C = 1u << P.lo_bits;
+        const uint32_t R = 1u << P.hi_bits, C = 1u << P.lo_bits, B = batch;
         char* row = (char*)s.d_arena;
-        char* col = row + (size_t)R * kXyzzBytes;
+        char* col = row + (size_t)R * B * kXyzzBytes;
         char* fin = (char*)s.d_final;
         const uint32_t rl = 1u << P.row_lo, rh = 1u << P.row_hi, cl = 1u << P.col_lo, ch = 1u << P.col_hi;
         TreeSumDesc stage1[2] = {
-            {s.d_buckets, row, R, C, C, 1},   // Row[hi] = sum_lo B[hi*C + lo]
-            {s.d_buckets, col, C, R, 1, C}};  // Col[lo] = sum_hi B[hi*C + lo]
+            {s.d_buckets, row, B * R, C, C, 1, B * R, 0},           // Row[p][hi] = sum_lo Bk[p][hi*C + lo]
+            {s.d_buckets, col, B * C, R, 1, C, C, (uint64_t)cfg.nb}};  // Col[p][lo] = sum_hi Bk[p][hi*C + lo]
         launch_tree_sums(st, stage1, 2);
         TreeSumDesc stage2[4] = {
-            {row, fin + (size_t)P.off_r2row * kXyzzBytes, rh, rl, rl, 1},
-            {row, fin + (size_t)P.off_c2row * kXyzzBytes, rl, rh, 1, rl},
-            {col, fin + (size_t)P.off_r2col * kXyzzBytes, ch, cl, cl, 1},
-            {col, fin + (size_t)P.off_c2col * kXyzzBytes, cl, ch, 1, cl}};
+            {row, fin + (size_t)P.off_r2row * B * kXyzzBytes, B * rh, rl, rl, 1, rh, R},
+            {row, fin + (size_t)P.off_c2row * B * kXyzzBytes, B * rl, rh, 1, rl, rl, R},
+            {col, fin + (size_t)P.off_r2col * B * kXyzzBytes, B * ch, cl, cl, 1, ch, C},
+            {col, fin + (size_t)P.off_c2col * B * kXyzzBytes, B * cl, ch, 1, cl, cl, C}};
         launch_tree_sums(st, stage2, 4);
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 5], st));
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_final, s.d_final, ctx->final_records * kXyzzBytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_final, s.d_final, ctx->final_records * batch * kXyzzBytes, hipMemcpyDeviceToHost,
+                                st));
     HIP_TRY(ctx, hipGetLastError());
     return KZG_OK;
 }
@@ -302,19 +309,19 @@ hf::P1 host_shift(hf::P1 p, uint32_t k) {
     for (uint32_t i = 0; i < k; i++) p = hf::p1_double(p);
     return p;
 }
-hf::P1 finish_msm(const kzg_ctx* ctx, const Slot& s) {
+hf::P1 finish_msm(const kzg_ctx* ctx, const Slot& s, uint32_t p = 0, uint32_t batch = 1) {
     const ReducePlan& P = ctx->plan;
     const uint64_t* f = s.h_final;
-    auto at = [&](uint32_t off) { return f + (size_t)off * kXyzzWords64; };
+    // section k of the final buffer is [batch][len_k]: polynomial p's block starts at off_k*batch + p*len_k
+    auto at = [&](uint32_t off, uint32_t len) { return f + ((size_t)off * batch + (size_t)p * len) * kXyzzWords64; };
+    const uint32_t rh = 1u << P.row_hi, rl = 1u << P.row_lo, ch = 1u << P.col_hi, cl = 1u << P.col_lo;
     // W(Row) = 2^row_lo * wsum(R2row) + wsum(C2row);  W(Col) likewise
-    hf::P1 w_row = hf::p1_add(host_shift(host_wsum(at(P.off_r2row), 1u << P.row_hi), P.row_lo),
-                              host_wsum(at(P.off_c2row), 1u << P.row_lo));
-    hf::P1 w_col = hf::p1_add(host_shift(host_wsum(at(P.off_r2col), 1u << P.col_hi), P.col_lo),
-                              host_wsum(at(P.off_c2col), 1u << P.col_lo));
+    hf::P1 w_row = hf::p1_add(host_shift(host_wsum(at(P.off_r2row, rh), rh), P.row_lo), host_wsum(at(P.off_c2row, rl), rl));
+    hf::P1 w_col = hf::p1_add(host_shift(host_wsum(at(P.off_r2col, ch), ch), P.col_lo), host_wsum(at(P.off_c2col, cl), cl));
     // sum_b b B_b = C * W(Row) + W(Col);  sum_b B_b = sum of R2row
     hf::P1 total = hf::p1_add(host_shift(w_row, P.lo_bits), w_col);
-    for (uint32_t k = 0; k < (1u << P.row_hi); k++)
-        total = hf::p1_add(total, hf::p1_from_xyzz(at(P.off_r2row + k)));
+    const uint64_t* r2 = at(P.off_r2row, rh);
+    for (uint32_t k = 0; k < rh; k++) total = hf::p1_add(total, hf::p1_from_xyzz(r2 + (size_t)k * kXyzzWords64));
     return hf::p1_normalize(total);
 }
 
@@ -497,6 +504,7 @@ static int submit_commit_locked(kzg_ctx* ctx, int slot, const uint32_t* d_scalar
     s.timing = ctx->timing;
     s.has_quotient = false;
     s.job_n = n;
+    s.job_batch = 1;
     s.tail_checked = tail_already_checked;
     std::memset(&s.times, 0, sizeof s.times);
     size_t n_msm = n < ctx->n ? n : ctx->n;
@@ -537,6 +545,7 @@ static int submit_open_locked(kzg_ctx* ctx, int slot, const uint32_t* d_coeffs, 
     if (rc) return rc;
     s.timing = ctx->timing;
     s.job_n = n;
+    s.job_batch = 1;
     s.has_quotient = true;
     s.tail_checked = false;
     std::memcpy(s.open_y, y, 32);
@@ -629,6 +638,66 @@ static int wait_locked(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
         return KZG_OK;
     }
     write_p1(out_p1, finish_msm(ctx, s));
+    return KZG_OK;
+}
+
+int kzg_set_max_batch(kzg_ctx* ctx, size_t max_batch) {
+    if (!ctx || max_batch == 0) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = drain_all(ctx);
+    if (rc) return rc;
+    for (auto& s : ctx->slots)
+        if (s.kind != SLOT_IDLE) return KZG_ERR_BUSY;
+    ctx->max_batch = (uint32_t)(max_batch > 1024 ? 1024 : max_batch);
+    return ctx->n ? setup_slots(ctx) : KZG_OK;  // workspaces are (re)sized when an SRS is resident
+}
+
+size_t kzg_max_batch(const kzg_ctx* ctx) { return ctx ? ctx->max_batch : 0; }
+
+int kzg_commit_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch,
+                            size_t stride_coeffs) {
+    if (!ctx || !d_coeffs || n == 0 || batch == 0 || stride_coeffs < n) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
+    if (slot < 0 || slot >= kNumSlots || batch > ctx->max_batch) return KZG_ERR_INVALID_ARG;
+    if (n > ctx->n) return KZG_ERR_DEGREE_TOO_HIGH;  // batches take truncated polynomials only
+    Slot& s = ctx->slots[slot];
+    if (s.kind != SLOT_IDLE) return KZG_ERR_BUSY;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    s.timing = ctx->timing;
+    s.has_quotient = false;
+    s.job_n = n;
+    s.job_batch = (uint32_t)batch;
+    s.tail_checked = true;
+    std::memset(&s.times, 0, sizeof s.times);
+    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    int rc = enqueue_msm(ctx, s, (const uint32_t*)d_coeffs, 1, n, 0, (uint32_t)batch, stride_coeffs);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
+    s.kind = SLOT_COMMIT;
+    return KZG_OK;
+}
+
+int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
+    if (!ctx || !out_p1s) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
+    Slot& s = ctx->slots[slot];
+    if (s.kind != SLOT_COMMIT || s.has_quotient || s.job_batch != batch) return KZG_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    s.kind = SLOT_IDLE;
+    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    if (s.timing) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, s.ev[0], s.ev[1]); s.times.digits_ms = ms;
+        (void)hipEventElapsedTime(&ms, s.ev[2], s.ev[3]); s.times.scatter_ms = ms;
+        (void)hipEventElapsedTime(&ms, s.ev[3], s.ev[4]); s.times.accumulate_ms = ms;
+        (void)hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;
+        (void)hipEventElapsedTime(&ms, s.ev[0], s.ev[5]); s.times.total_ms = ms;
+    }
+    for (uint32_t p = 0; p < s.job_batch; p++) write_p1(out_p1s + 18 * (size_t)p, finish_msm(ctx, s, p, s.job_batch));
     return KZG_OK;
 }
 

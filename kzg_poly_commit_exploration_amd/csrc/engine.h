@@ -24,13 +24,16 @@ struct MsmConfig {
 MsmConfig choose_msm_config(size_t n_points);
 
 // ---- msm_kernels.hip --------------------------------------------------------------------
-// scalar recoding + two-level LDS counting sort: fills d_offs[0..nb] (d_offs[nb] = number of
-// references) and d_sorted (bucket-major table references, index | sign << 31).
-//   d_cnt: sort_count_entries(n_max, cfg) u32;  d_block_sums: 1024 u32;  d_pairs: n * W u64
-uint32_t sort_count_entries(uint32_t n, MsmConfig cfg);
-void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n,
-                        uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt, uint32_t* d_block_sums,
-                        uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted);
+// scalar recoding + two-level LDS counting sort of `batch` polynomials of n terms at once (polynomial p
+// at d_scalars + p * stride scalars; its buckets are [p * nb, (p+1) * nb)): fills
+// d_offs[0 .. batch*nb] (last = number of references) and d_sorted (bucket-major table references,
+// index | sign << 31).  d_cnt: sort_count_entries(max_batch, cfg) u32; d_block_sums: 1024 u32;
+// d_pairs: batch * n * W u64.  batch <= sort_max_batch(cfg).
+uint32_t sort_count_entries(uint32_t max_batch, MsmConfig cfg);
+uint32_t sort_max_batch(MsmConfig cfg);
+void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n, uint32_t batch,
+                        uint64_t stride, uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt,
+                        uint32_t* d_block_sums, uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted);
 // bucket accumulation (dominant kernel): one lane per segment of L sorted references
 constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on ceil(max_refs / accumulate_segment_len(max_refs))
 uint32_t accumulate_segment_len(uint64_t max_refs);
@@ -43,11 +46,14 @@ void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, 
                             uint32_t* d_heavy_count /* pre-zeroed */);
 // out[g] = sum_{q<len} in[g*gstride + q*estride], XYZZ records: log-depth tree per group;
 // up to four independent jobs per launch
+// group g reads in[(g / inner) * ostride + (g % inner) * gstride + q * estride], q < len
 struct TreeSumDesc {
     const void* in;
     void* out;
     uint32_t groups, len;
     uint64_t gstride, estride;
+    uint32_t inner;    // groups per outer block (= groups when there is no batch dimension)
+    uint64_t ostride;  // record stride between outer blocks
 };
 void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count);
 

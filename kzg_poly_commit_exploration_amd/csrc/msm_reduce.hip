@@ -61,8 +61,8 @@ constexpr int kTreeBlock = 256;
 struct TreeJob {
     const uint4* in;
     uint4* out;
-    uint32_t groups, len, lanes_per_group, first_block;
-    uint64_t gstride, estride;
+    uint32_t groups, len, lanes_per_group, first_block, inner;
+    uint64_t gstride, estride, ostride;
 };
 struct TreeJobs {
     TreeJob j[4];
@@ -83,8 +83,9 @@ __global__ void __launch_bounds__(kTreeBlock) k_tree_sum(TreeJobs jobs) {
     const uint32_t l = t & (lanes_per_group - 1);
     XYZZ acc = XYZZ::inf();
     if (g < J.groups) {
+        const uint64_t base = (uint64_t)(g / J.inner) * J.ostride + (uint64_t)(g % J.inner) * J.gstride;
         for (uint32_t q = l; q < J.len; q += lanes_per_group) {
-            XYZZ b = load_xyzz(J.in + (size_t)(g * J.gstride + q * J.estride) * 12);
+            XYZZ b = load_xyzz(J.in + (size_t)(base + q * J.estride) * 12);
             xyzz_add(acc, b);
         }
     }
@@ -127,6 +128,8 @@ void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count) {
         jobs.j[i].first_block = blocks;
         jobs.j[i].gstride = descs[i].gstride;
         jobs.j[i].estride = descs[i].estride;
+        jobs.j[i].inner = descs[i].inner ? descs[i].inner : descs[i].groups;
+        jobs.j[i].ostride = descs[i].ostride;
         blocks += (descs[i].groups + gpb - 1) / gpb;
     }
     if (!blocks) return;

@@ -37,7 +37,7 @@ MsmConfig choose_msm_config(size_t n) {
 // k * P = (r - k) * (-P).  Returns true when the point has to be negated.  Besides halving the
 // range this makes the reference's "negative" i128 inputs (r - |a|, src/scalar.rs:27-48) as cheap
 // as the positive ones: their upper windows become zero digits, which are skipped.
-KZG_DEV bool load_scalar(const uint32_t* d_scalars, uint32_t i, int is_mont, u32 k[8]) {
+KZG_DEV bool load_scalar(const uint32_t* d_scalars, uint64_t i, int is_mont, u32 k[8]) {
     const uint4* p = reinterpret_cast<const uint4*>(d_scalars) + 2 * (size_t)i;
     uint4 lo = p[0], hi = p[1];
     Fr a;
@@ -109,60 +109,84 @@ struct SortGeom {
     uint32_t coarse_bins;  // nb >> fine_bits
 };
 
-static SortGeom sort_geometry(uint32_t n, MsmConfig cfg) {
+// `total` scalars (batch * n) into `nb_total` buckets (batch * 2^(c-1): polynomial-major bucket ids)
+static SortGeom sort_geometry(uint64_t total, uint32_t nb_total, MsmConfig cfg) {
     SortGeom g;
-    uint32_t tile = (n + 255) / 256;                      // at most 256 tiles
+    uint32_t tile = (uint32_t)((total + 255) / 256);      // at most 256 tiles (bounds the count table)
     tile = ((tile + kSortBlock - 1) / kSortBlock) * kSortBlock;
     if (tile < (uint32_t)kSortBlock) tile = kSortBlock;
     g.tile = tile;
-    g.tiles = (n + tile - 1) / tile;
+    g.tiles = (uint32_t)((total + tile - 1) / tile);
     g.fine_bits = cfg.c - 1 < 8 ? cfg.c - 1 : 8;
-    g.coarse_bins = cfg.nb >> g.fine_bits;
+    g.coarse_bins = nb_total >> g.fine_bits;
     return g;
 }
 
-uint32_t sort_count_entries(uint32_t n, MsmConfig cfg) {
-    // a commitment shorter than the SRS may use more (smaller) tiles than the full length: bound by 256
-    SortGeom g = sort_geometry(n, cfg);
-    return g.coarse_bins * 257u;
+uint32_t sort_max_batch(MsmConfig cfg) {
+    uint32_t fine_bits = cfg.c - 1 < 8 ? cfg.c - 1 : 8;
+    uint32_t b = (uint32_t)kMaxCoarse / (cfg.nb >> fine_bits);
+    return b < 1 ? 1 : b;
 }
 
+uint32_t sort_count_entries(uint32_t max_batch, MsmConfig cfg) {
+    // coarse bins x tiles, tiles bounded by 256 (+1) whatever the length of the commitment
+    uint32_t fine_bits = cfg.c - 1 < 8 ? cfg.c - 1 : 8;
+    return ((cfg.nb * max_batch) >> fine_bits) * 257u;
+}
+
+// Batch addressing shared by passes 1 and 2: global scalar index g -> polynomial p = g / n, term i = g % n;
+// coefficients of polynomial p start at d_scalars + p * stride (in scalars); its buckets at p * nb.
+struct BatchGeom {
+    uint32_t n;       // terms per polynomial
+    uint32_t batch;   // polynomials
+    uint64_t stride;  // scalars between consecutive polynomials
+    uint32_t nb;      // buckets per polynomial
+};
+
 __global__ void __launch_bounds__(kSortBlock) k_sort_count(const uint32_t* __restrict__ d_scalars, int is_mont,
-                                                           uint32_t n, uint32_t c, uint32_t W, uint32_t tile,
+                                                           BatchGeom bg, uint32_t c, uint32_t W, uint32_t tile,
                                                            uint32_t tiles, uint32_t fine_bits, uint32_t coarse_bins,
                                                            uint32_t* __restrict__ d_cnt) {
     __shared__ u32 s_hist[kMaxCoarse];
     for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) s_hist[q] = 0;
     __syncthreads();
-    const uint32_t base = blockIdx.x * tile;
+    const uint64_t base = (uint64_t)blockIdx.x * tile;
+    const uint64_t total = (uint64_t)bg.n * bg.batch;
     for (uint32_t off = threadIdx.x; off < tile; off += kSortBlock) {
-        uint32_t i = base + off;
-        if (i >= n) break;
+        uint64_t g = base + off;
+        if (g >= total) break;
+        uint32_t p = (uint32_t)(g / bg.n);
+        uint32_t i = (uint32_t)(g - (uint64_t)p * bg.n);
         u32 k[8];
-        (void)load_scalar(d_scalars, i, is_mont, k);
-        for_each_digit(k, c, W, [&](uint32_t, u32 mag, bool) { atomicAdd(&s_hist[(mag - 1) >> fine_bits], 1u); });
+        (void)load_scalar(d_scalars, p * bg.stride + i, is_mont, k);
+        const u32 pb = p * bg.nb;
+        for_each_digit(k, c, W, [&](uint32_t, u32 mag, bool) { atomicAdd(&s_hist[(pb + mag - 1) >> fine_bits], 1u); });
     }
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) d_cnt[(size_t)q * tiles + blockIdx.x] = s_hist[q];
 }
 
 __global__ void __launch_bounds__(kSortBlock) k_sort_spread(const uint32_t* __restrict__ d_scalars, int is_mont,
-                                                            uint32_t n, uint32_t table_stride, uint32_t c, uint32_t W,
+                                                            BatchGeom bg, uint32_t table_stride, uint32_t c, uint32_t W,
                                                             uint32_t tile, uint32_t tiles, uint32_t fine_bits,
                                                             uint32_t coarse_bins, const uint32_t* __restrict__ d_cnt_scanned,
                                                             uint64_t* __restrict__ d_pairs) {
     __shared__ u32 s_cur[kMaxCoarse];
     for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) s_cur[q] = d_cnt_scanned[(size_t)q * tiles + blockIdx.x];
     __syncthreads();
-    const uint32_t base = blockIdx.x * tile;
+    const uint64_t base = (uint64_t)blockIdx.x * tile;
+    const uint64_t total = (uint64_t)bg.n * bg.batch;
     const u32 fine_mask = (1u << fine_bits) - 1u;
     for (uint32_t off = threadIdx.x; off < tile; off += kSortBlock) {
-        uint32_t i = base + off;
-        if (i >= n) break;
+        uint64_t g = base + off;
+        if (g >= total) break;
+        uint32_t p = (uint32_t)(g / bg.n);
+        uint32_t i = (uint32_t)(g - (uint64_t)p * bg.n);
         u32 k[8];
-        const bool flip = load_scalar(d_scalars, i, is_mont, k);
+        const bool flip = load_scalar(d_scalars, p * bg.stride + i, is_mont, k);
+        const u32 pb = p * bg.nb;
         for_each_digit(k, c, W, [&](uint32_t j, u32 mag, bool neg) {
-            u32 b = mag - 1;
+            u32 b = pb + mag - 1;
             u32 pos = atomicAdd(&s_cur[b >> fine_bits], 1u);
             u32 ref = (j * table_stride + i) | ((neg != flip) ? 0x80000000u : 0u);
             d_pairs[pos] = ((uint64_t)(b & fine_mask) << 32) | ref;
@@ -285,18 +309,20 @@ static void scan_inplace(hipStream_t s, uint32_t* d_buf, uint32_t count, uint32_
     hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(kScanBlock), 0, s, d_buf, count, d_block_sums);
 }
 
-void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, uint32_t n, uint32_t table_stride,
-                        MsmConfig cfg, uint32_t* d_cnt, uint32_t* d_block_sums, uint64_t* d_pairs, uint32_t* d_offs,
-                        uint32_t* d_sorted) {
-    if (n == 0) return;
-    SortGeom g = sort_geometry(n, cfg);
-    hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, n, cfg.c, cfg.W, g.tile,
+void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, uint32_t n, uint32_t batch,
+                        uint64_t stride, uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt, uint32_t* d_block_sums,
+                        uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted) {
+    if (n == 0 || batch == 0) return;
+    const uint32_t nb_total = cfg.nb * batch;
+    SortGeom g = sort_geometry((uint64_t)n * batch, nb_total, cfg);
+    BatchGeom bg{n, batch, stride, cfg.nb};
+    hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, cfg.c, cfg.W, g.tile,
                        g.tiles, g.fine_bits, g.coarse_bins, d_cnt);
-    scan_inplace(s, d_cnt, g.coarse_bins * g.tiles, d_block_sums, d_offs + cfg.nb);  // total pairs -> offs[nb]
-    hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, n, table_stride, cfg.c,
+    scan_inplace(s, d_cnt, g.coarse_bins * g.tiles, d_block_sums, d_offs + nb_total);  // total refs -> offs[nb_total]
+    hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg.c,
                        cfg.W, g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_pairs);
     hipLaunchKernelGGL(k_sort_fine, dim3(g.coarse_bins), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
-                       g.coarse_bins, d_offs + cfg.nb, d_offs, d_sorted);
+                       g.coarse_bins, d_offs + nb_total, d_offs, d_sorted);
 }
 
 }  // namespace kzg

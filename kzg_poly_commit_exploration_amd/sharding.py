@@ -22,18 +22,18 @@ def shard_range(n, rank, world):
 _BUFFERS = {}
 
 
-def _buffers(world, device):
-    """Persistent staging buffers: pinned host in/out plus device in/out (18 x int64 per rank)."""
+def _buffers(world, device, count=1):
+    """Persistent staging buffers: pinned host in/out plus device in/out (count x 18 int64 per rank)."""
     import torch
 
-    key = (world, str(device))
+    key = (world, str(device), count)
     if key not in _BUFFERS:
         pin = device is not None
-        h_in = torch.empty(18, dtype=torch.int64, pin_memory=pin)
-        h_out = torch.empty(18 * world, dtype=torch.int64, pin_memory=pin)
+        h_in = torch.empty(18 * count, dtype=torch.int64, pin_memory=pin)
+        h_out = torch.empty(18 * count * world, dtype=torch.int64, pin_memory=pin)
         if device is not None:
-            d_in = torch.empty(18, dtype=torch.int64, device=device)
-            d_out = torch.empty(18 * world, dtype=torch.int64, device=device)
+            d_in = torch.empty(18 * count, dtype=torch.int64, device=device)
+            d_out = torch.empty(18 * count * world, dtype=torch.int64, device=device)
         else:
             d_in, d_out = h_in, h_out
         _BUFFERS[key] = (h_in, h_out, d_in, d_out)
@@ -62,6 +62,29 @@ def allgather_partials(partial, device=None, group=None):
         h_out.copy_(torch.cat(gathered))
     arr = h_out.numpy().view(np.uint64).reshape(world, 18)
     return [G1Point(arr[r].copy()) for r in range(world)]
+
+
+def allgather_partial_batch(partials, device=None, group=None):
+    """Batch form: `partials` = this rank's list of B G1Points; returns B lists of `world` points
+    (one exchange of B x 144 bytes per rank)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    count = len(partials)
+    h_in, h_out, d_in, d_out = _buffers(world, device, count)
+    h_in.numpy().reshape(count, 18)[:] = np.stack([p.p1 for p in partials]).view(np.int64)
+    if device is not None:
+        d_in.copy_(h_in, non_blocking=True)
+        dist.all_gather_into_tensor(d_out, d_in, group=group)
+        h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+    else:
+        gathered = [torch.empty_like(h_in) for _ in range(world)]
+        dist.all_gather(gathered, h_in, group=group)
+        h_out.copy_(torch.cat(gathered))
+    arr = h_out.numpy().view(np.uint64).reshape(world, count, 18)
+    return [[G1Point(arr[r, b].copy()) for r in range(world)] for b in range(count)]
 
 
 def combine(partials):

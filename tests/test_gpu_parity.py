@@ -349,6 +349,39 @@ def test_degree_2_20_commit_and_proof_golden(engines, oracle, golden):
     assert rc == 0 and np.array_equal(q, q_want)
 
 
+def test_batched_commit_equals_individual(oracle, golden):
+    """kzg_commit_batch_submit: B polynomials through one pass of the kernels (polynomial-major bucket
+    ids) must give the same B commitments as B separate calls -- uniform, skewed and zero polynomials."""
+    secret = bytes.fromhex(golden["secret_be"])
+    n = 5000
+    eng = K.SetupArtifactsGenerator(secret).take(n)
+    try:
+        b = eng.set_max_batch(6)
+        assert 1 <= b <= 6 and eng.max_batch() == b
+        rnd = random.Random(77)
+        polys = [K.scalars_to_limbs([rnd.randrange(K.R_MODULUS) for _ in range(n)]),
+                 oracle.bench_coefficients(n),
+                 K.scalars_to_limbs([7] * n),
+                 np.zeros((n, 4), dtype=np.uint64),
+                 K.scalars_to_limbs([rnd.randrange(-(1 << 127), 1 << 127) for _ in range(n)]),
+                 K.scalars_to_limbs([K.R_MODULUS - 1] * n)][:b]
+        single = [eng.commit_limbs(p).compress() for p in polys]
+        srs = eng.srs_read(0, n)
+        for p, got in zip(polys[:3], single[:3]):
+            rc, want = oracle.commit_pippenger(p, srs, threads=8)
+            assert rc == 0 and got == oracle.p1_compress(want)
+        batched = [g.compress() for g in eng.commit_batch_limbs(polys)]
+        assert batched == single
+        # a shorter batch and a batch of shorter polynomials on the same engine
+        assert [g.compress() for g in eng.commit_batch_limbs(polys[:2])] == single[:2]
+        short = [p[:1234] for p in polys[:3]]
+        assert [g.compress() for g in eng.commit_batch_limbs(short)] == [eng.commit_limbs(p).compress() for p in short]
+        with pytest.raises(K.KzgError):
+            eng.commit_batch_limbs(polys + polys)  # more than max_batch
+    finally:
+        eng.close()
+
+
 # ---------------------------------------------------------------- 2^22 (BASELINE config 4 size, one GPU)
 
 def test_degree_2_22_commit_and_proof_golden(oracle, golden):
