@@ -29,6 +29,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# HIP multiplexes streams onto 4 hardware queues by default.  The engine uses 4 streams of its own (3
+# slots + the accumulation stream); with torch's and RCCL's streams on top, two of them would share a
+# queue and a slot's reduction would serialise in front of the next accumulation kernel (1.2 ms bubbles,
+# tools/gaps.py).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 DEGREE = 1 << 20
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_MAD_PEAK_T = 19.66        # v_mad_u64_u32 at a quarter of 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (T/s)

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/kzg_mi355x.h"
@@ -697,7 +698,20 @@ int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
         (void)hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;
         (void)hipEventElapsedTime(&ms, s.ev[0], s.ev[5]); s.times.total_ms = ms;
     }
-    for (uint32_t p = 0; p < s.job_batch; p++) write_p1(out_p1s + 18 * (size_t)p, finish_msm(ctx, s, p, s.job_batch));
+    // host tails of the batch in parallel (each is ~150 point operations and one inversion)
+    const uint32_t B = s.job_batch;
+    const uint32_t nthreads = B < 8 ? B : 8;
+    auto work = [&](uint32_t t) {
+        for (uint32_t p = t; p < B; p += nthreads) write_p1(out_p1s + 18 * (size_t)p, finish_msm(ctx, s, p, B));
+    };
+    if (nthreads <= 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < nthreads; t++) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+    }
     return KZG_OK;
 }
 
