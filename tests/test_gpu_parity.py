@@ -121,6 +121,30 @@ def test_kate_proof_random_i128_like_reference_lib_tests(engines, oracle, golden
         assert rc == 0 and ev.generate_proof(poly, eng).compress() == oracle.p1_compress(pf)
 
 
+def test_gpu_proofs_pass_the_references_pairing_check(oracle, twin):
+    """The reference's acceptance criterion (src/lib.rs:16-33): commit -> evaluate -> generate_proof ->
+    verify_proof == true, with a fresh random secret and random i128 inputs, the pairing evaluated by the
+    independent restatement in oracle/pairing_twin.py.  A commitment or proof off by one bit fails."""
+    import pairing_twin as PT
+
+    rnd = random.Random(4242)
+    for degree in (1, 2, 64, rnd.randrange(100, 2000)):
+        secret = bytes(rnd.randrange(256) for _ in range(32))
+        setup = K.SetupArtifactsGenerator(secret).take(degree + 1)
+        try:
+            poly = K.Polynomial.try_from([rnd.randrange(-(1 << 127), 1 << 127) for _ in range(degree + 1)])
+            z = K.Scalar.from_i128(rnd.randrange(-(1 << 127), 1 << 127))
+            commitment = poly.commit(setup)
+            evaluation = poly.evaluate(z, setup)
+            proof = evaluation.generate_proof(poly, setup)
+            C = twin.g1_uncompress(commitment.compress())
+            pi = twin.g1_uncompress(proof.compress())
+            assert PT.verify_proof(C, pi, z.v, evaluation.result.v, secret), degree
+            assert not PT.verify_proof(C, pi, z.v, (evaluation.result.v + 1) % K.R_MODULUS, secret)
+        finally:
+            setup.close()
+
+
 def test_commit_le_bytes_entry_point(engines, oracle, golden):
     eng = engines.bench_srs(SMALL_N)
     c = oracle.bench_coefficients(1025)
