@@ -7,10 +7,13 @@
 
 namespace kzg {
 
-// One affine SRS / table point in HBM: x then y, 12 + 12 little-endian u32 limbs, Montgomery.
-// 96 bytes, 16-byte aligned, (0,0) = infinity.  Table layout: window-major, T[j * n + i] =
-// 2^(c*j) * SRS[i]  (j < W), so window 0 is the SRS itself.
-constexpr size_t kAffineBytes = 96;
+// One affine SRS / table point in HBM: x then y, 12 + 12 little-endian u32 limbs, Montgomery
+// (96 bytes of payload), (0,0) = infinity, padded to a 128-byte record so that every random gather of
+// the accumulation kernel touches exactly one 128-byte line (at 96 B a record straddles 1.5 lines on
+// average and the kernel fetched 2x its payload; PMC figures in DESIGN.md).  Table layout:
+// window-major, T[j * n + i] = 2^(c*j) * SRS[i]  (j < W), so window 0 is the SRS itself.
+constexpr size_t kAffineBytes = 128;
+constexpr size_t kAffineU4 = kAffineBytes / 16;  // record stride in uint4 units
 // One XYZZ accumulator in HBM: X, Y, ZZ, ZZZ, 4 x 12 u32 = 192 bytes.
 constexpr size_t kXyzzBytes = 192;
 constexpr size_t kXyzzWords64 = 24;

@@ -22,7 +22,7 @@ namespace kzg {
 constexpr int kAccumBlock = 256;
 
 KZG_DEV Affine load_affine(const uint4* __restrict__ table, uint32_t idx) {
-    const uint4* p = table + (size_t)idx * 6;
+    const uint4* p = table + (size_t)idx * kAffineU4;
     uint4 a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3], a4 = p[4], a5 = p[5];
     Affine r;
     r.x.l[0] = a0.x; r.x.l[1] = a0.y; r.x.l[2] = a0.z; r.x.l[3] = a0.w;

@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(64) k_normalize(const uint4* __restrict__ in, 
     for (uint32_t i = hi; i-- > lo;) {
         const uint4* rec = in + (size_t)i * REC;
         Fp d = load_fp(rec + DEN);
-        uint4* o = out + (size_t)i * 6;
+        uint4* o = out + (size_t)i * kAffineU4;
         if (d.is_zero()) {  // infinity -> (0, 0)
             Fp zero = Fp::zero();
             store_fp(o, zero);
@@ -111,7 +111,7 @@ __global__ void __launch_bounds__(64) k_window_double(const uint4* __restrict__ 
                                                       uint4* __restrict__ out_xyzz) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    XYZZ a = xyzz_from_affine(load_affine(prev + (size_t)i * 6));
+    XYZZ a = xyzz_from_affine(load_affine(prev + (size_t)i * kAffineU4));
 #pragma unroll 1
     for (uint32_t k = 0; k < c; k++) a = xyzz_dbl(a);
     store_xyzz(out_xyzz + (size_t)i * 12, a);
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(64) k_window_double(const uint4* __restrict__ 
 __global__ void __launch_bounds__(64) k_affine_to_p1(const uint4* __restrict__ aff, uint32_t n, uint4* __restrict__ out) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Affine a = load_affine(aff + (size_t)i * 6);
+    Affine a = load_affine(aff + (size_t)i * kAffineU4);
     uint4* o = out + (size_t)i * 9;
     store_fp(o, a.x);
     store_fp(o + 3, a.y);
@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(64) k_srs_points(FrArg8 secret, uint64_t first
         for (int t = 0; t < 7; t++) k.l[t] = (k.l[t] >> 8) | (k.l[t + 1] << 24);
         k.l[7] >>= 8;
         if (d) {
-            Affine p = load_affine(gtable + (size_t)(w * kGDigits + (d - 1)) * 6);
+            Affine p = load_affine(gtable + (size_t)(w * kGDigits + (d - 1)) * kAffineU4);
             xyzz_madd(acc, p, false);
         }
     }
