@@ -93,10 +93,11 @@ struct kzg_ctx {
     // the light sort / reduction kernels of the other slots run beside it on the slots' own streams.
     hipStream_t heavy_stream = nullptr;
     bool serialize_accum = true;   // KZG_SERIALIZE_ACCUM=0 lets accumulation kernels of different slots overlap
-    // LDS reserved per accumulation workgroup (KZG_ACCUM_LDS_KB, default none): occupancy-shaping knob for
-    // experiments.  54 KB (2 waves/SIMD) lets the reduction kernels of other slots run beside the
-    // accumulation but slows it by 5 %; with 8 slots in flight the full-occupancy kernel wins.
-    uint32_t accum_lds_bytes = 0;
+    // LDS reserved per accumulation workgroup (KZG_ACCUM_LDS_KB overrides): 41 KB admits three workgroups
+    // per CU = 3 waves/SIMD (the grid is sized to 3 x 256 x 256 lanes, one resident round), which leaves
+    // one wave slot and 128 VGPRs per SIMD to the light kernels of the other slots (sort, quotient).
+    // Measured against full occupancy (0 KB, 262144 lanes): commitments/s -1 %, opening proofs/s +6 %.
+    uint32_t accum_lds_bytes = 41u * 1024u;
     bool slots_ready = false;
     bool timing = false;
 };

@@ -123,11 +123,12 @@ __global__ void __launch_bounds__(kAccumBlock, 4) k_bucket_accumulate(const uint
 }
 
 uint32_t accumulate_segment_len(uint64_t max_refs) {
-    // one segment per resident lane of the chip (256 CUs x 4 SIMDs x 4 waves x 64 lanes): the whole grid
-    // is resident at once, a second partially filled round of workgroups would cost up to 2x.
+    // one segment per resident lane of the chip (256 CUs x 4 SIMDs x 3 waves x 64 lanes, see the LDS
+    // reservation in api.hip): the whole grid is resident at once; a second, partially filled round of
+    // workgroups would cost up to 2x.  KZG_ACCUM_LANES overrides for experiments.
     static const uint64_t lanes = [] {
         const char* v = std::getenv("KZG_ACCUM_LANES");
-        uint64_t l = v ? std::strtoull(v, nullptr, 10) : 262144ull;
+        uint64_t l = v ? std::strtoull(v, nullptr, 10) : 196608ull;
         return l < 64 ? 262144ull : (l > 262144ull ? 262144ull : l);
     }();
     uint64_t L = (max_refs + lanes - 1) / lanes;
