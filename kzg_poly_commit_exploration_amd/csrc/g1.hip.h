@@ -11,7 +11,9 @@
 
 namespace kzg {
 
+#ifndef KZG_SB
 #define KZG_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 // Fp products of the group law go through fmul/fsqr.  With KZG_MUL_CALL they are real function
 // calls (one copy of the ~1000-instruction multiplier in the instruction cache instead of ten per
