@@ -259,6 +259,66 @@ KZG_DEV Fe<F> fe_to_mont(const Fe<F>& a) {
 typedef Fe<FpParams> Fp;
 typedef Fe<FrParams> Fr;
 
+// ---- lazily reduced Fp: representatives in [0, 2p) ------------------------------------------------
+// A Montgomery product of two values below 2p is below (4p^2 + R p)/R < 1.41 p, so the conditional
+// subtraction that ends every multiplication can be dropped if additions and subtractions wrap at 2p
+// instead of p (2p < 2^382 still fits twelve limbs with room for a sum of two).  Zero then has two
+// representatives, 0 and p.  Values are made canonical (fp_canon) only where they leave the device
+// arithmetic: SRS read-back and the handful of partial sums handed to the host.
+KZG_DEV u32 fp_2p(int i) {
+    constexpr u32 V[12] = {0xffff5556u, 0x73fdffffu, 0x62a7ffffu, 0x3d57fffdu, 0xed61ec48u, 0xce61a541u,
+                           0xe70a257eu, 0xc8ee9709u, 0x869759aeu, 0x96374f6cu, 0x72ffcd34u, 0x340223d4u};
+    return V[i];
+}
+KZG_DEV Fp fp_canon(Fp a) {  // [0, 2p) -> [0, p)
+    cond_sub_mod(a, 0u);
+    return a;
+}
+KZG_DEV Fp fp_add_lz(const Fp& a, const Fp& b) {
+    Fp r;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = addc(a.l[i], b.l[i], c);  // < 4p < 2^384: no carry out
+    u32 d[12];
+    u32 br = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) d[i] = subb(r.l[i], fp_2p(i), br);
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = br ? r.l[i] : d[i];
+    return r;
+}
+KZG_DEV Fp fp_sub_lz(const Fp& a, const Fp& b) {
+    Fp r;
+    u32 br = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = subb(a.l[i], b.l[i], br);
+    u32 mask = 0u - br;
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = addc(r.l[i], fp_2p(i) & mask, c);
+    return r;
+}
+KZG_DEV Fp fp_neg_lz(const Fp& a) {  // 2p - a, and 0 stays 0
+    Fp r;
+    u32 nz = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) nz |= a.l[i];
+    u32 mask = nz ? 0xffffffffu : 0u;
+    u32 br = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) r.l[i] = subb(fp_2p(i) & mask, a.l[i], br);
+    return r;
+}
+KZG_DEV bool fp_is_zero_lz(const Fp& a) {  // a == 0 or a == p
+    u32 z = 0, e = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        z |= a.l[i];
+        e |= a.l[i] ^ FpParams::mod(i);
+    }
+    return z == 0 || e == 0;
+}
+
 // ---- rolled (loop, scratch-resident) Fp arithmetic for the exceptional branches -------------
 // The group law's rare branches (doubling when a bucket receives the point it already holds)
 // must not set the register budget of the hot loop, so they run on small non-unrolled routines

@@ -18,13 +18,31 @@ namespace kzg {
 // Fp products of the group law go through fmul/fsqr.  With KZG_MUL_CALL they are real function
 // calls (one copy of the ~1000-instruction multiplier in the instruction cache instead of ten per
 // addition); otherwise they are inlined.  Chosen per kernel from measurements.
-#ifdef KZG_MUL_CALL
-static __device__ __noinline__ Fp fmul(Fp a, Fp b) { return fe_mul_fips(a, b); }
-static __device__ __noinline__ Fp fsqr(Fp a) { return fe_mul_fips(a, a); }
+// KZG_LAZY_FP (set for every device translation unit by the Makefile, or not at all): coordinates live
+// in [0, 2p) and the multiplier skips its final conditional subtraction (field.hip.h).
+#ifdef KZG_LAZY_FP
+#define KZG_FMUL_IMPL(a, b) fe_mul_fips<FpParams, true>(a, b)
+KZG_DEV Fp fadd(const Fp& a, const Fp& b) { return fp_add_lz(a, b); }
+KZG_DEV Fp fsub(const Fp& a, const Fp& b) { return fp_sub_lz(a, b); }
+KZG_DEV Fp fneg(const Fp& a) { return fp_neg_lz(a); }
+KZG_DEV bool fzero(const Fp& a) { return fp_is_zero_lz(a); }
+KZG_DEV Fp fcanon(const Fp& a) { return fp_canon(a); }
 #else
-KZG_DEV Fp fmul(const Fp& a, const Fp& b) { return fe_mul_fips(a, b); }
-KZG_DEV Fp fsqr(const Fp& a) { return fe_mul_fips(a, a); }
+#define KZG_FMUL_IMPL(a, b) fe_mul_fips<FpParams, false>(a, b)
+KZG_DEV Fp fadd(const Fp& a, const Fp& b) { return fe_add(a, b); }
+KZG_DEV Fp fsub(const Fp& a, const Fp& b) { return fe_sub(a, b); }
+KZG_DEV Fp fneg(const Fp& a) { return fe_neg(a); }
+KZG_DEV bool fzero(const Fp& a) { return a.is_zero(); }
+KZG_DEV Fp fcanon(const Fp& a) { return a; }
 #endif
+#ifdef KZG_MUL_CALL
+static __device__ __noinline__ Fp fmul(Fp a, Fp b) { return KZG_FMUL_IMPL(a, b); }
+static __device__ __noinline__ Fp fsqr(Fp a) { return KZG_FMUL_IMPL(a, a); }
+#else
+KZG_DEV Fp fmul(const Fp& a, const Fp& b) { return KZG_FMUL_IMPL(a, b); }
+KZG_DEV Fp fsqr(const Fp& a) { return KZG_FMUL_IMPL(a, a); }
+#endif
+KZG_DEV Fp fdbl(const Fp& a) { return fadd(a, a); }
 
 struct Affine {  // Montgomery x, y;  (0, 0) encodes the point at infinity (it is not on the curve)
     Fp x, y;
@@ -46,7 +64,7 @@ struct XYZZ {
         r.ZZZ = Fp::zero();
         return r;
     }
-    KZG_DEV bool is_inf() const { return ZZ.is_zero(); }
+    KZG_DEV bool is_inf() const { return fzero(ZZ); }
 };
 
 KZG_DEV XYZZ xyzz_from_affine(const Affine& p) {
@@ -61,9 +79,9 @@ KZG_DEV XYZZ xyzz_from_affine(const Affine& p) {
 
 // 2 * a (dbl-2008-s-1), fully unrolled: for kernels whose main operation is doubling.
 KZG_DEV XYZZ xyzz_dbl(const XYZZ& a) {
-    if (a.is_inf() || a.Y.is_zero()) return XYZZ::inf();
+    if (a.is_inf() || fzero(a.Y)) return XYZZ::inf();
     XYZZ r;
-    Fp U = fe_dbl(a.Y);
+    Fp U = fdbl(a.Y);
     Fp V = fsqr(U);
     KZG_SB();
     Fp W = fmul(U, V);
@@ -74,14 +92,14 @@ KZG_DEV XYZZ xyzz_dbl(const XYZZ& a) {
     KZG_SB();
     Fp M = fsqr(a.X);
     KZG_SB();
-    M = fe_add(fe_dbl(M), M);
-    r.X = fe_sub(fe_sub(fsqr(M), S), S);
+    M = fadd(fdbl(M), M);
+    r.X = fsub(fsub(fsqr(M), S), S);
     KZG_SB();
     r.ZZZ = fmul(W, a.ZZZ);
     KZG_SB();
     Fp WY = fmul(W, a.Y);
     KZG_SB();
-    r.Y = fe_sub(fmul(M, fe_sub(S, r.X)), WY);
+    r.Y = fsub(fmul(M, fsub(S, r.X)), WY);
     KZG_SB();
     return r;
 }
@@ -113,17 +131,18 @@ static __device__ __noinline__ void xyzz_dbl_rare(u32* io) {
 
 // acc = 2 * acc through the rare path (caller has already excluded infinity / Y = 0 handled here)
 KZG_DEV void xyzz_dbl_inplace_rare(XYZZ& acc) {
-    if (acc.is_inf() || acc.Y.is_zero()) {
+    if (acc.is_inf() || fzero(acc.Y)) {
         acc = XYZZ::inf();
         return;
     }
     u32 io[48];
+    const Fp cx = fcanon(acc.X), cy = fcanon(acc.Y), czz = fcanon(acc.ZZ), czzz = fcanon(acc.ZZZ);  // rolled code is strict mod p
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        io[i] = acc.X.l[i];
-        io[12 + i] = acc.Y.l[i];
-        io[24 + i] = acc.ZZ.l[i];
-        io[36 + i] = acc.ZZZ.l[i];
+        io[i] = cx.l[i];
+        io[12 + i] = cy.l[i];
+        io[24 + i] = czz.l[i];
+        io[36 + i] = czzz.l[i];
     }
     xyzz_dbl_rare(io);
 #pragma unroll
@@ -140,7 +159,7 @@ KZG_DEV void xyzz_dbl_inplace_rare(XYZZ& acc) {
 // otherwise interleaves the ten independent-looking products and spills).
 KZG_DEV void xyzz_madd(XYZZ& acc, const Affine& p_in, bool neg) {
     if (p_in.is_inf()) return;
-    Fp py = neg ? fe_neg(p_in.y) : p_in.y;
+    Fp py = neg ? fneg(p_in.y) : p_in.y;
     if (acc.is_inf()) {
         acc.X = p_in.x;
         acc.Y = py;
@@ -148,12 +167,12 @@ KZG_DEV void xyzz_madd(XYZZ& acc, const Affine& p_in, bool neg) {
         acc.ZZZ = Fp::one();
         return;
     }
-    Fp P = fe_sub(fmul(p_in.x, acc.ZZ), acc.X);  // U2 - X1
+    Fp P = fsub(fmul(p_in.x, acc.ZZ), acc.X);  // U2 - X1
     KZG_SB();
-    Fp R = fe_sub(fmul(py, acc.ZZZ), acc.Y);  // S2 - Y1
+    Fp R = fsub(fmul(py, acc.ZZZ), acc.Y);  // S2 - Y1
     KZG_SB();
-    if (P.is_zero()) {
-        if (R.is_zero()) {
+    if (fzero(P)) {
+        if (fzero(R)) {
             xyzz_dbl_inplace_rare(acc);  // acc == p as group elements: 2*acc
         } else {
             acc = XYZZ::inf();
@@ -172,9 +191,9 @@ KZG_DEV void xyzz_madd(XYZZ& acc, const Affine& p_in, bool neg) {
     KZG_SB();
     Fp YP = fmul(acc.Y, PPP);
     KZG_SB();
-    Fp X3 = fe_sub(fe_sub(fsqr(R), PPP), fe_dbl(Q));
+    Fp X3 = fsub(fsub(fsqr(R), PPP), fdbl(Q));
     KZG_SB();
-    acc.Y = fe_sub(fmul(R, fe_sub(Q, X3)), YP);
+    acc.Y = fsub(fmul(R, fsub(Q, X3)), YP);
     acc.X = X3;
     KZG_SB();
 }
@@ -188,14 +207,14 @@ KZG_DEV void xyzz_add(XYZZ& acc, const XYZZ& b) {
     }
     Fp U1 = fmul(acc.X, b.ZZ);
     KZG_SB();
-    Fp P = fe_sub(fmul(b.X, acc.ZZ), U1);
+    Fp P = fsub(fmul(b.X, acc.ZZ), U1);
     KZG_SB();
     Fp S1 = fmul(acc.Y, b.ZZZ);
     KZG_SB();
-    Fp R = fe_sub(fmul(b.Y, acc.ZZZ), S1);
+    Fp R = fsub(fmul(b.Y, acc.ZZZ), S1);
     KZG_SB();
-    if (P.is_zero()) {
-        if (R.is_zero()) {
+    if (fzero(P)) {
+        if (fzero(R)) {
             // equal operands: frequent in the running-sum reduction when buckets are empty
 #ifdef KZG_FAST_DBL_IN_ADD
             acc = xyzz_dbl(acc);
@@ -219,9 +238,9 @@ KZG_DEV void xyzz_add(XYZZ& acc, const XYZZ& b) {
     KZG_SB();
     Fp YP = fmul(S1, PPP);
     KZG_SB();
-    Fp X3 = fe_sub(fe_sub(fsqr(R), PPP), fe_dbl(Q));
+    Fp X3 = fsub(fsub(fsqr(R), PPP), fdbl(Q));
     KZG_SB();
-    acc.Y = fe_sub(fmul(R, fe_sub(Q, X3)), YP);
+    acc.Y = fsub(fmul(R, fsub(Q, X3)), YP);
     acc.X = X3;
     KZG_SB();
 }
@@ -229,7 +248,7 @@ KZG_DEV void xyzz_add(XYZZ& acc, const XYZZ& b) {
 // Jacobian (X, Y, Z) as stored in blst_p1 -> XYZZ (no inversion): ZZ = Z^2, ZZZ = Z^3.
 KZG_DEV XYZZ xyzz_from_jacobian(const Fp& X, const Fp& Y, const Fp& Z) {
     XYZZ r;
-    if (Z.is_zero()) return XYZZ::inf();
+    if (fzero(Z)) return XYZZ::inf();
     r.X = X;
     r.Y = Y;
     r.ZZ = fsqr(Z);

@@ -177,6 +177,10 @@ inline P1 p1_from_xyzz(const uint64_t* w) {
     std::memcpy(Y.l, w + 6, 48);
     std::memcpy(ZZ.l, w + 12, 48);
     std::memcpy(ZZZ.l, w + 18, 48);
+    // the device keeps coordinates lazily reduced in [0, 2p): make them canonical first
+    uint64_t br;
+    for (Fp* f : {&X, &Y, &ZZ, &ZZZ})
+        if (geq(*f, kP)) *f = raw_sub(*f, kP, br);
     if (ZZ.is_zero()) return p1_inf();
     P1 r;
     r.x = X * ZZ;

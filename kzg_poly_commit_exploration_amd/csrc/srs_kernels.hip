@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64) k_normalize(const uint4* __restrict__ in, 
     Fp run = Fp::one();
     for (uint32_t i = lo; i < hi; i++) {
         Fp d = load_fp(in + (size_t)i * REC + DEN);
-        if (!d.is_zero()) run = fmul(run, d);
+        if (!fzero(d)) run = fmul(run, d);
         store_fp(prefix + (size_t)i * 3, run);
     }
     Fp inv = fp_inv_call(run);
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64) k_normalize(const uint4* __restrict__ in, 
         const uint4* rec = in + (size_t)i * REC;
         Fp d = load_fp(rec + DEN);
         uint4* o = out + (size_t)i * kAffineU4;
-        if (d.is_zero()) {  // infinity -> (0, 0)
+        if (fzero(d)) {  // infinity -> (0, 0)
             Fp zero = Fp::zero();
             store_fp(o, zero);
             store_fp(o + 3, zero);
@@ -122,8 +122,8 @@ __global__ void __launch_bounds__(64) k_affine_to_p1(const uint4* __restrict__ a
     if (i >= n) return;
     Affine a = load_affine(aff + (size_t)i * kAffineU4);
     uint4* o = out + (size_t)i * 9;
-    store_fp(o, a.x);
-    store_fp(o + 3, a.y);
+    store_fp(o, fcanon(a.x));  // canonical residues for the host (blst_p1 layout)
+    store_fp(o + 3, fcanon(a.y));
     Fp z = a.is_inf() ? Fp::zero() : Fp::one();
     store_fp(o + 6, z);
 }
