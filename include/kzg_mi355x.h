@@ -133,6 +133,13 @@ size_t kzg_max_batch(const kzg_ctx* ctx);
 int kzg_commit_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch,
                             size_t stride_coeffs);
 int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s /* batch x 18 */, size_t batch);
+/* Batched Evaluation::generate_proof (reference src/polynomial.rs:260-269): polynomial p is opened at
+ * zs[p] with claimed value ys[p] (4 x uint64 Montgomery each); one quotient scan per polynomial, one
+ * batched MSM over the quotients.  n >= 2, n - 1 <= kzg_srs_len.  kzg_wait_open_batch fills one status per
+ * polynomial (KZG_OK, KZG_ERR_CONSTANT_POLY, KZG_ERR_REMAINDER) and the proofs of those that are KZG_OK. */
+int kzg_open_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch,
+                          size_t stride_coeffs, const uint64_t* zs, const uint64_t* ys);
+int kzg_wait_open_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s /* batch x 18 */, int* statuses, size_t batch);
 
 /* raw device memory helpers so a non-HIP host (Rust, Python) can stage device-resident inputs */
 int kzg_dev_alloc(kzg_ctx* ctx, size_t bytes, void** out_dptr);
@@ -150,6 +157,11 @@ int kzg_g1_sum(const uint64_t* p1s, size_t k, uint64_t out_p1[18]);
 /* ZCash 48-byte compression = what the reference's `Serialize for G1Point` emits
  * (reference src/curves.rs:99-110 -> blst_p1_compress).  The parity comparator. */
 int kzg_g1_compress(const uint64_t p1[18], uint8_t out[48]);
+
+/* Inverse: what the reference's `Deserialize for G1Point` obtains from blst_p1_uncompress +
+ * blst_p1_from_affine (reference src/curves.rs:112-183), e.g. to ingest the CLI's setup.json.  On-curve
+ * check only, as blst.  Next-row component. */
+int kzg_g1_uncompress(const uint8_t in[48], uint64_t out_p1[18]);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 

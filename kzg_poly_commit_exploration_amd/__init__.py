@@ -42,6 +42,7 @@ ABI_SYMBOLS = [
     "kzg_commit", "kzg_commit_le_bytes", "kzg_open", "kzg_quotient", "kzg_evaluate",
     "kzg_num_slots", "kzg_commit_submit", "kzg_open_submit", "kzg_wait",
     "kzg_set_max_batch", "kzg_max_batch", "kzg_commit_batch_submit", "kzg_wait_batch",
+    "kzg_open_batch_submit", "kzg_wait_open_batch", "kzg_g1_uncompress",
     "kzg_dev_alloc", "kzg_dev_free", "kzg_dev_upload", "kzg_dev_download",
     "kzg_g1_sum", "kzg_g1_compress", "kzg_set_timing", "kzg_get_times", "kzg_msm_config",
 ]
@@ -101,6 +102,9 @@ def load_library():
         "kzg_max_batch": (sz, [vp]),
         "kzg_commit_batch_submit": (i, [vp, i, vp, sz, sz, sz]),
         "kzg_wait_batch": (i, [vp, i, vp, sz]),
+        "kzg_open_batch_submit": (i, [vp, i, vp, sz, sz, sz, vp, vp]),
+        "kzg_wait_open_batch": (i, [vp, i, vp, vp, sz]),
+        "kzg_g1_uncompress": (i, [u8p, vp]),
         "kzg_dev_alloc": (i, [vp, sz, C.POINTER(vp)]),
         "kzg_dev_free": (i, [vp, vp]),
         "kzg_dev_upload": (i, [vp, vp, vp, sz]),
@@ -232,6 +236,12 @@ class G1Point:
         rc = load_library().kzg_g1_compress(_ptr(self.p1), C.cast(out, C.c_void_p))
         _check(rc)
         return bytes(out)
+
+    @staticmethod
+    def uncompress(data):  # Deserialize for G1Point, src/curves.rs:112-183
+        out = np.zeros(18, dtype=np.uint64)
+        _check(load_library().kzg_g1_uncompress(bytes(data), _ptr(out)))
+        return G1Point(out)
 
     def is_infinity(self):
         return not self.p1[12:18].any()
@@ -387,6 +397,31 @@ class Engine:
         out = np.zeros((batch, 18), dtype=np.uint64)
         _check(self._lib.kzg_wait_batch(self._h, slot, _ptr(out), batch), self._h)
         return [G1Point(out[i]) for i in range(batch)]
+
+    def open_batch_limbs(self, polys, zs, ys):
+        """Batched generate_proof: returns a list of G1Point or KzgError per polynomial."""
+        polys = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in polys]
+        n, b = polys[0].shape[0], len(polys)
+        assert all(p.shape[0] == n for p in polys) and len(zs) == b and len(ys) == b
+        flat = np.concatenate(polys)
+        zl = np.ascontiguousarray(np.stack([z.limbs() for z in zs]))
+        yl = np.ascontiguousarray(np.stack([y.limbs() for y in ys]))
+        dptr = self.dev_alloc(flat.nbytes)
+        try:
+            self.dev_upload(dptr, flat)
+            _check(self._lib.kzg_open_batch_submit(self._h, 0, C.c_void_p(dptr), n, b, n, _ptr(zl), _ptr(yl)), self._h)
+            out = np.zeros((b, 18), dtype=np.uint64)
+            st = np.zeros(b, dtype=np.int32)
+            _check(self._lib.kzg_wait_open_batch(self._h, 0, _ptr(out), _ptr(st), b), self._h)
+        finally:
+            self.dev_free(dptr)
+        res = []
+        for i in range(b):
+            if st[i] == KZG_OK:
+                res.append(G1Point(out[i]))
+            else:
+                res.append(KzgError(int(st[i]), self._lib.kzg_strerror(int(st[i])).decode()))
+        return res
 
     def commit_batch_limbs(self, polys):
         """Commits several coefficient arrays (each (n, 4) uint64, same n) in one batched pass."""

@@ -63,6 +63,10 @@ struct Slot {
     uint32_t* d_block = nullptr;
     uint32_t* d_small = nullptr;  // [0..1] flags, [8..15] P(z), [16..23] c0, [24] tail flag, [25] heavy count
     uint32_t* h_small = nullptr;  // pinned mirror
+    uint32_t* d_bsmall = nullptr;  // batched openings: 32 words per polynomial, same layout as d_small[0..31]
+    uint32_t* h_bsmall = nullptr;
+    size_t bsmall_cap = 0;
+    std::vector<uint32_t> open_ys;  // y of every polynomial of a batched opening (8 words each)
     // state of the job in flight
     SlotKind kind = SLOT_IDLE;
     size_t job_n = 0;
@@ -391,6 +395,8 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
         free_slot_poly(s);
         if (s.d_small) hipFree(s.d_small);
         if (s.h_small) hipHostFree(s.h_small);
+        if (s.d_bsmall) hipFree(s.d_bsmall);
+        if (s.h_bsmall) hipHostFree(s.h_bsmall);
         for (auto& e : s.ev)
             if (e) hipEventDestroy(e);
         if (s.done) hipEventDestroy(s.done);
@@ -716,6 +722,95 @@ int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
     return KZG_OK;
 }
 
+// Batched Evaluation::generate_proof: one quotient scan per polynomial (each with its own z, y), then
+// ONE batched MSM over the `batch` quotients.
+int kzg_open_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch, size_t stride_coeffs,
+                          const uint64_t* zs, const uint64_t* ys) {
+    if (!ctx || !d_coeffs || !zs || !ys || n < 2 || batch == 0 || stride_coeffs < n) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
+    if (slot < 0 || slot >= kNumSlots || batch > ctx->max_batch) return KZG_ERR_INVALID_ARG;
+    if (n - 1 > ctx->n) return KZG_ERR_DEGREE_TOO_HIGH;  // batches take truncated polynomials only
+    Slot& s = ctx->slots[slot];
+    if (s.kind != SLOT_IDLE) return KZG_ERR_BUSY;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = ensure_poly(ctx, s, n * batch);
+    if (rc) return rc;
+    if (s.bsmall_cap < batch) {
+        HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+        if (s.d_bsmall) hipFree(s.d_bsmall);
+        if (s.h_bsmall) hipHostFree(s.h_bsmall);
+        HIP_TRY(ctx, hipMalloc(&s.d_bsmall, batch * 32 * 4));
+        HIP_TRY(ctx, hipHostMalloc(&s.h_bsmall, batch * 32 * 4));
+        s.bsmall_cap = batch;
+    }
+    s.timing = ctx->timing;
+    s.job_n = n;
+    s.job_batch = (uint32_t)batch;
+    s.has_quotient = true;
+    s.tail_checked = true;
+    s.open_ys.assign((const uint32_t*)ys, (const uint32_t*)ys + 8 * batch);
+    std::memset(&s.times, 0, sizeof s.times);
+    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    HIP_TRY(ctx, hipMemsetAsync(s.d_bsmall, 0, batch * 32 * 4, s.stream));
+    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[6], s.stream));
+    const size_t nq = n - 1;
+    for (size_t p = 0; p < batch; p++) {
+        const uint32_t* cp = (const uint32_t*)d_coeffs + p * stride_coeffs * 8;
+        uint32_t zw[8];
+        std::memcpy(zw, zs + 4 * p, 32);
+        uint32_t* sm = s.d_bsmall + p * 32;
+        PolyScratch sc{s.d_chunk, s.d_block, sm, sm + 8};  // scratch re-used in stream order
+        launch_quotient(s.stream, cp, (uint32_t)n, zw, s.d_q + p * nq * 8, sc);
+        HIP_TRY(ctx, hipMemcpyAsync(sm + 16, cp, 32, hipMemcpyDeviceToDevice, s.stream));  // c0
+    }
+    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[7], s.stream));
+    rc = enqueue_msm(ctx, s, s.d_q, 1, nq, 0, (uint32_t)batch, nq);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_bsmall, s.d_bsmall, batch * 32 * 4, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
+    s.kind = SLOT_OPEN;
+    return KZG_OK;
+}
+
+int kzg_wait_open_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, int* statuses, size_t batch) {
+    if (!ctx || !out_p1s || !statuses) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
+    Slot& s = ctx->slots[slot];
+    if (s.kind != SLOT_OPEN || !s.has_quotient || s.job_batch != batch || s.open_ys.size() != 8 * batch)
+        return KZG_ERR_INVALID_ARG;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    s.kind = SLOT_IDLE;
+    HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    if (s.timing) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, s.ev[6], s.ev[7]); s.times.quotient_ms = ms;
+        (void)hipEventElapsedTime(&ms, s.ev[0], s.ev[1]); s.times.digits_ms = ms;
+        (void)hipEventElapsedTime(&ms, s.ev[3], s.ev[4]); s.times.accumulate_ms = ms;
+        (void)hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;
+        (void)hipEventElapsedTime(&ms, s.ev[6], s.ev[5]); s.times.total_ms = ms;
+    }
+    const uint32_t B = s.job_batch;
+    const hf::P1 inf = hf::p1_inf();
+    for (uint32_t p = 0; p < B; p++) {
+        const uint32_t* hs = s.h_bsmall + p * 32;
+        const uint32_t* y = s.open_ys.data() + 8 * p;
+        uint64_t* out = out_p1s + 18 * (size_t)p;
+        // reference order: divide_by_root's two errors (src/polynomial.rs:159-167, 184-192)
+        if (!(hs[0] & 1u)) {  // constant polynomial after truncation
+            if (std::memcmp(hs + 16, y, 32) != 0) statuses[p] = KZG_ERR_CONSTANT_POLY;
+            else { statuses[p] = KZG_OK; write_p1(out, inf); }
+            continue;
+        }
+        if (std::memcmp(hs + 8, y, 32) != 0) { statuses[p] = KZG_ERR_REMAINDER; continue; }
+        statuses[p] = KZG_OK;
+        write_p1(out, finish_msm(ctx, s, p, B));
+    }
+    s.open_ys.clear();
+    return KZG_OK;
+}
+
 int kzg_wait(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
     if (!ctx || !out_p1) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -895,6 +990,14 @@ int kzg_g1_compress(const uint64_t p1[18], uint8_t out[48]) {
     hf::P1 p;
     std::memcpy(&p, p1, sizeof p);
     hf::p1_compress(out, p);
+    return KZG_OK;
+}
+
+int kzg_g1_uncompress(const uint8_t in[48], uint64_t out_p1[18]) {
+    if (!in || !out_p1) return KZG_ERR_INVALID_ARG;
+    hf::P1 p;
+    if (!hf::p1_uncompress(p, in)) return KZG_ERR_INVALID_ARG;
+    write_p1(out_p1, p);
     return KZG_OK;
 }
 

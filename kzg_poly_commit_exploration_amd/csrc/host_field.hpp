@@ -9,6 +9,7 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <initializer_list>
 
 namespace kzg_host {
 
@@ -200,6 +201,46 @@ inline void p1_compress(uint8_t out[48], const P1& p) {  // ZCash encoding (refe
         for (int k = 0; k < 8; ++k) out[47 - (8 * i + k)] = (uint8_t)(x.l[i] >> (8 * k));
     out[0] |= 0x80;
     if (!(y == kHalf) && geq(y, kHalf)) out[0] |= 0x20;
+}
+
+// inverse of p1_compress: what the reference's `Deserialize for G1Point` does through blst_p1_uncompress
+// (src/curves.rs:112-183).  On-curve check only (as blst), y = (x^3 + 4)^((p+1)/4) since p = 3 mod 4.
+inline bool p1_uncompress(P1& out, const uint8_t in[48]) {
+    if (!(in[0] & 0x80)) return false;          // compressed form only
+    if (in[0] & 0x40) {                          // infinity: all other bits must be clear
+        for (int i = 0; i < 48; ++i)
+            if ((i == 0 ? (in[0] & 0x3F) : in[i]) != 0) return false;
+        out = p1_inf();
+        return true;
+    }
+    Fp x;
+    std::memset(&x, 0, sizeof x);
+    for (int i = 0; i < 48; ++i) {
+        uint8_t b = i == 0 ? (uint8_t)(in[0] & 0x1F) : in[i];
+        x.l[(47 - i) >> 3] |= (uint64_t)b << (8 * ((47 - i) & 7));
+    }
+    if (geq(x, kP)) return false;
+    static const Fp kR2 = {{0xf4df1f341c341746ULL, 0x0a76e6a609d104f1ULL, 0x8de5476c4c95b6d5ULL,
+                            0x67eb88a9939d83c0ULL, 0x9a793e85b519952dULL, 0x11988fe592cae3aaULL}};
+    static const Fp kB = {{0xaa270000000cfff3ULL, 0x53cc0032fc34000aULL, 0x478fe97a6b0a807fULL,
+                           0xb1d37ebee6ba24d7ULL, 0x8ec9733bbf78ab2fULL, 0x09d645513d83de7eULL}};  // 4
+    static const Fp kSqrtE = {{0xee7fbfffffffeaabULL, 0x07aaffffac54ffffULL, 0xd9cc34a83dac3d89ULL,
+                               0xd91dd2e13ce144afULL, 0x92c6e9ed90d2eb35ULL, 0x0680447a8e5ff9a6ULL}};  // (p+1)/4
+    Fp xm = x * kR2;
+    Fp y2 = sqr(xm) * xm + kB;
+    Fp acc = kOne, base = y2;
+    for (int i = 0; i < 381; ++i) {
+        if ((kSqrtE.l[i >> 6] >> (i & 63)) & 1) acc = acc * base;
+        base = sqr(base);
+    }
+    if (!(sqr(acc) == y2)) return false;         // not on the curve
+    Fp yc = from_mont(acc);
+    bool larger = !(yc == kHalf) && geq(yc, kHalf);
+    if (larger != ((in[0] & 0x20) != 0)) acc = neg(acc);
+    out.x = xm;
+    out.y = acc;
+    out.z = kOne;
+    return true;
 }
 
 }  // namespace kzg_host

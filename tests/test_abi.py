@@ -54,6 +54,18 @@ def test_host_g1_helpers_against_oracle(oracle, golden):
     assert K.G1Point(scaled[0]).compress() == oracle.p1_compress(pts[3])
 
 
+def test_g1_uncompress_round_trip(oracle, golden):
+    g = oracle.p1_generator()
+    for k in (1, 2, 3, 0xDEADBEEF, K.R_MODULUS - 1):
+        pt = oracle.p1_mult(g, k)
+        c = oracle.p1_compress(pt)
+        back = K.G1Point.uncompress(c)
+        assert back.compress() == c and oracle.p1_equal(back.p1, pt)
+    assert K.G1Point.uncompress(bytes.fromhex(golden["constants"]["compress_inf"])).is_infinity()
+    with pytest.raises(K.KzgError):
+        K.G1Point.uncompress(bytes([0x80]) + bytes(46) + bytes([0x01]))  # x = 1 is not on the curve
+
+
 def test_no_cpu_fallback():
     """Without a HIP device the engine cannot be created: the product has no CPU path."""
     try:

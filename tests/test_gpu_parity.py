@@ -406,6 +406,35 @@ def test_batched_commit_equals_individual(oracle, golden):
         eng.close()
 
 
+def test_batched_openings_equal_individual(oracle, golden):
+    """kzg_open_batch_submit (BASELINE config 5 shape): per-polynomial z and y, per-polynomial status."""
+    secret = bytes.fromhex(golden["secret_be"])
+    n = 3000
+    eng = K.SetupArtifactsGenerator(secret).take(n)
+    try:
+        b = eng.set_max_batch(4)
+        rnd = random.Random(91)
+        polys = [K.scalars_to_limbs([rnd.randrange(K.R_MODULUS) for _ in range(n)]) for _ in range(3)]
+        polys.append(K.scalars_to_limbs([5] + [0] * (n - 1)))  # constant polynomial with trailing zeros
+        polys = polys[:b]
+        zs = [K.Scalar(rnd.randrange(K.R_MODULUS)) for _ in polys]
+        ys = [eng.evaluate_limbs(p, z) for p, z in zip(polys, zs)]
+        ys[1] = K.Scalar(ys[1].v + 1)  # wrong claimed value -> remainder error for polynomial 1 only
+        got = eng.open_batch_limbs(polys, zs, ys)
+        for i, (p, z, y) in enumerate(zip(polys, zs, ys)):
+            try:
+                want = eng.open_limbs(p, z, y)
+            except K.KzgError as e:
+                assert isinstance(got[i], K.KzgError) and got[i].status == e.status, i
+                continue
+            assert got[i].compress() == want.compress(), i
+        assert isinstance(got[1], K.KzgError) and got[1].status == K.KZG_ERR_REMAINDER
+        if b >= 4:
+            assert got[3].is_infinity()  # (5 - 5) / (x - z) = 0
+    finally:
+        eng.close()
+
+
 # ---------------------------------------------------------------- 2^22 (BASELINE config 4 size, one GPU)
 
 def test_degree_2_22_commit_and_proof_golden(oracle, golden):
