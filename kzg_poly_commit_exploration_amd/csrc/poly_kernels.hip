@@ -122,11 +122,13 @@ __global__ void __launch_bounds__(1024) k_poly_blocks(uint32_t* __restrict__ d_b
         uint32_t b = tile * 1024 + t;
         Fr v = b < nblocks ? load_fr(d_block + (size_t)b * 8) : Fr::zero();
         v = block_suffix_scan<1024>(v, zb, lds);
-        // add the carry from the tiles above: zb^(1024 - t) * carry
+        // add the carry from the tiles above: zb^(1024 - t) * carry (nothing to add for the top tile,
+        // which is the only tile up to 2^21 coefficients)
         Fr carry;
 #pragma unroll
         for (int i = 0; i < 8; i++) carry.l[i] = s_carry[i];
-        Fr full = fe_add(v, fe_mul(fr_pow_u32(zb, 1024 - t), carry));
+        Fr full = v;
+        if (tile + 1 < ntiles) full = fe_add(v, fe_mul(fr_pow_u32(zb, 1024 - t), carry));
         // full = S at the start of block b.  carry-in of block b is S at the start of block b+1.
 #pragma unroll
         for (int i = 0; i < 8; i++) lds[i * 1024 + t] = full.l[i];
