@@ -266,6 +266,54 @@ def test_skewed_scalars_heavy_buckets(engines, oracle, golden):
         assert eng.commit_limbs(c).compress() == oracle.p1_compress(want)
 
 
+def test_randomized_differential_against_oracle(oracle, golden):
+    """Seeded sweep over odd sizes and scalar distributions: exercises tile / bin / segment boundaries of
+    the sort and of the segmented accumulation, sub-SRS lengths, and the quotient at every size."""
+    secret = bytes.fromhex(golden["secret_be"])
+    rnd = random.Random(20260101)
+    r = K.R_MODULUS
+
+    def gen(kind, n):
+        if kind == "uniform":
+            return [rnd.randrange(r) for _ in range(n)]
+        if kind == "i128":
+            return [K.Scalar.from_i128(rnd.randrange(-(1 << 127), 1 << 127)).v for _ in range(n)]
+        if kind == "small":
+            return [rnd.randrange(1 << 12) for _ in range(n)]
+        if kind == "sparse":
+            return [rnd.randrange(r) if rnd.random() < 0.05 else 0 for _ in range(n)]
+        if kind == "two_values":
+            a, b = rnd.randrange(r), rnd.randrange(r)
+            return [a if rnd.random() < 0.5 else b for _ in range(n)]
+        raise AssertionError(kind)
+
+    for srs_n in (1, 2, 3, 129, 1000, 4097, 20011, 40009):
+        eng = K.SetupArtifactsGenerator(secret).take(srs_n)
+        try:
+            srs = eng.srs_read(0, srs_n)
+            for kind in ("uniform", "i128", "small", "sparse", "two_values"):
+                n = srs_n if rnd.random() < 0.5 else rnd.randrange(1, srs_n + 1)
+                ints = gen(kind, n)
+                if ints[-1] == 0:
+                    ints[-1] = 1  # keep the polynomial's length (the reference truncates trailing zeros)
+                c = K.scalars_to_limbs(ints)
+                rc, want = oracle.commit_pippenger(c, srs[:n], threads=8)
+                assert rc == 0
+                assert eng.commit_limbs(c).compress() == oracle.p1_compress(want), (srs_n, kind, n)
+                if n >= 2:
+                    z = K.Scalar(rnd.randrange(r))
+                    y = eng.evaluate_limbs(c, z)
+                    zo, yo = oracle.fr_from_int(z.v), oracle.fr_from_int(y.v)
+                    assert oracle.fr_to_int(oracle.poly_evaluate(c, zo)) == y.v
+                    rc, q = oracle.quotient(c, zo, yo)
+                    assert rc == 0
+                    rc, wantp = oracle.commit_pippenger(q, srs[: len(q)], threads=8) if len(q) else (0, np.zeros(18, dtype=np.uint64))
+                    assert rc == 0
+                    assert eng.open_limbs(c, z, y).compress() == oracle.p1_compress(wantp), (srs_n, kind, n)
+        finally:
+            eng.close()
+
+
 # ---------------------------------------------------------------- 2^16 (BASELINE config 2)
 
 def test_degree_2_16_commit_and_proof(engines, oracle, golden):
