@@ -99,6 +99,10 @@ def main():
     ap.add_argument("--slots", type=int, default=0, help="stream slots kept in flight (0 = all the engine has)")
     ap.add_argument("--batch", type=int, default=0,
                     help="polynomials per step, one batched pass of the kernels (0 = number of GPUs)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend; gloo (host tensors) only for rehearsing N > 1 on one GPU")
+    ap.add_argument("--device", type=int, default=-1,
+                    help="rehearsal: put every rank on this device instead of LOCAL_RANK (needs --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (RCCL) even at world size 1: exercises the exchange path on one GPU")
     args = ap.parse_args()
@@ -117,6 +121,8 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if args.device >= 0:
+        local_rank = args.device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -125,7 +131,11 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    xdev = dev if args.backend == "nccl" else None   # where the exchanged partials live
 
     def barrier():
         if dist is not None:
@@ -165,7 +175,7 @@ def main():
         for k, v in t.items():
             phase_ms.setdefault(k, []).append(v)
         if dist is not None:
-            partials = [combine(ps) for ps in allgather_partial_batch(partials, device=dev)]
+            partials = [combine(ps) for ps in allgather_partial_batch(partials, device=xdev)]
         results.extend(partials)
 
     def run(steps):
@@ -189,7 +199,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
