@@ -117,6 +117,16 @@ namespace {
         }                                                                                           \
     } while (0)
 
+// scope guards for the setup paths (several HIP_TRY early returns)
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) hipFree(p); }
+};
+struct TmpStream {
+    hipStream_t s = nullptr;
+    ~TmpStream() { if (s) hipStreamDestroy(s); }
+};
+
 void free_slot_msm(Slot& s) {
     hipFree(s.d_cnt); hipFree(s.d_offs); hipFree(s.d_block_sums); hipFree(s.d_pairs); hipFree(s.d_sorted);
     hipFree(s.d_buckets); hipFree(s.d_part_a); hipFree(s.d_part_b); hipFree(s.d_heavy_list); hipFree(s.d_arena); hipFree(s.d_final);
@@ -131,6 +141,17 @@ void free_slot_poly(Slot& s) {
     hipFree(s.d_stage); hipFree(s.d_q); hipFree(s.d_chunk); hipFree(s.d_block);
     s.d_stage = s.d_q = s.d_chunk = s.d_block = nullptr;
     s.poly_cap = 0;
+}
+
+// stream, events and the small flag buffers of a slot (what kzg_quotient / kzg_evaluate need without an SRS)
+int ensure_slot_basics(kzg_ctx* ctx, Slot& s) {
+    if (s.stream) return KZG_OK;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    for (auto& e : s.ev) HIP_TRY(ctx, hipEventCreate(&e));
+    HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    HIP_TRY(ctx, hipMalloc(&s.d_small, 64 * 4));
+    HIP_TRY(ctx, hipHostMalloc(&s.h_small, 64 * 4));
+    return KZG_OK;
 }
 
 int ensure_poly(kzg_ctx* ctx, Slot& s, size_t n) {
@@ -175,12 +196,9 @@ int setup_slots(kzg_ctx* ctx) {
     const size_t pairs = (size_t)cfg.W * ctx->n * B;
     for (int i = 0; i < kNumSlots; i++) {
         Slot& s = ctx->slots[i];
-        if (!s.stream) {
-            HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-            for (auto& e : s.ev) HIP_TRY(ctx, hipEventCreate(&e));
-            HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-            HIP_TRY(ctx, hipMalloc(&s.d_small, 64 * 4));
-            HIP_TRY(ctx, hipHostMalloc(&s.h_small, 64 * 4));
+        {
+            int rcb = ensure_slot_basics(ctx, s);
+            if (rcb) return rcb;
         }
         if (!s.sorted_ev) {
             HIP_TRY(ctx, hipEventCreateWithFlags(&s.sorted_ev, hipEventDisableTiming));
@@ -429,20 +447,16 @@ int kzg_srs_load_g1(kzg_ctx* ctx, const void* first_g1, size_t stride, size_t n)
     // gather the strided blst_p1 values, upload, normalise to affine = window 0
     std::vector<uint64_t> packed(n * 18);
     for (size_t i = 0; i < n; i++) std::memcpy(&packed[i * 18], (const char*)first_g1 + i * stride, 144);
-    void *d_jac = nullptr, *d_prefix = nullptr, *d_xyzz = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_jac, n * 144));
-    HIP_TRY(ctx, hipMalloc(&d_prefix, n * 48));
-    HIP_TRY(ctx, hipMalloc(&d_xyzz, n * kXyzzBytes));
-    hipStream_t st = nullptr;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    HIP_TRY(ctx, hipMemcpyAsync(d_jac, packed.data(), n * 144, hipMemcpyHostToDevice, st));
+    DevBuf d_jac, d_prefix, d_xyzz;
+    HIP_TRY(ctx, hipMalloc(&d_jac.p, n * 144));
+    HIP_TRY(ctx, hipMalloc(&d_prefix.p, n * 48));
+    HIP_TRY(ctx, hipMalloc(&d_xyzz.p, n * kXyzzBytes));
+    TmpStream st;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipMemcpyAsync(d_jac.p, packed.data(), n * 144, hipMemcpyHostToDevice, st.s));
     ctx->n = n;
-    launch_jacobian_to_affine(st, d_jac, (uint32_t)n, ctx->d_table, d_prefix);
-    rc = build_tables(ctx, st, d_xyzz, d_prefix);
-    hipStreamDestroy(st);
-    hipFree(d_jac);
-    hipFree(d_prefix);
-    hipFree(d_xyzz);
+    launch_jacobian_to_affine(st.s, d_jac.p, (uint32_t)n, ctx->d_table, d_prefix.p);
+    rc = build_tables(ctx, st.s, d_xyzz.p, d_prefix.p);
     if (rc) {
         ctx->n = 0;
         return rc;
@@ -463,19 +477,15 @@ int kzg_srs_generate_g1(kzg_ctx* ctx, const uint8_t secret_be[32], uint64_t firs
         raw[w] = ((uint32_t)b[0] << 24) | ((uint32_t)b[1] << 16) | ((uint32_t)b[2] << 8) | (uint32_t)b[3];
     }
     size_t tmp_records = n > 32 * 255 ? n : 32 * 255;
-    void *d_gtable = nullptr, *d_prefix = nullptr, *d_xyzz = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_gtable, srs_gtable_bytes()));
-    HIP_TRY(ctx, hipMalloc(&d_prefix, tmp_records * 48));
-    HIP_TRY(ctx, hipMalloc(&d_xyzz, tmp_records * kXyzzBytes));
-    hipStream_t st = nullptr;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    DevBuf d_gtable, d_prefix, d_xyzz;
+    HIP_TRY(ctx, hipMalloc(&d_gtable.p, srs_gtable_bytes()));
+    HIP_TRY(ctx, hipMalloc(&d_prefix.p, tmp_records * 48));
+    HIP_TRY(ctx, hipMalloc(&d_xyzz.p, tmp_records * kXyzzBytes));
+    TmpStream st;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
     ctx->n = n;
-    launch_srs_generate(st, raw, first, (uint32_t)n, d_gtable, d_xyzz, d_prefix, ctx->d_table);
-    rc = build_tables(ctx, st, d_xyzz, d_prefix);
-    hipStreamDestroy(st);
-    hipFree(d_gtable);
-    hipFree(d_prefix);
-    hipFree(d_xyzz);
+    launch_srs_generate(st.s, raw, first, (uint32_t)n, d_gtable.p, d_xyzz.p, d_prefix.p, ctx->d_table);
+    rc = build_tables(ctx, st.s, d_xyzz.p, d_prefix.p);
     if (rc) {
         ctx->n = 0;
         return rc;
@@ -490,13 +500,12 @@ int kzg_srs_read_g1(kzg_ctx* ctx, size_t index, size_t count, uint64_t* out_p1) 
     if (index > ctx->n || count > ctx->n - index) return KZG_ERR_INVALID_ARG;
     if (!count) return KZG_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    void* d_p1 = nullptr;
-    HIP_TRY(ctx, hipMalloc(&d_p1, count * 144));
+    DevBuf d_p1;
+    HIP_TRY(ctx, hipMalloc(&d_p1.p, count * 144));
     hipStream_t st = ctx->slots[0].stream;
-    launch_affine_to_p1(st, (const char*)ctx->d_table + index * kAffineBytes, (uint32_t)count, d_p1);
-    HIP_TRY(ctx, hipMemcpyAsync(out_p1, d_p1, count * 144, hipMemcpyDeviceToHost, st));
+    launch_affine_to_p1(st, (const char*)ctx->d_table + index * kAffineBytes, (uint32_t)count, d_p1.p);
+    HIP_TRY(ctx, hipMemcpyAsync(out_p1, d_p1.p, count * 144, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    hipFree(d_p1);
     return KZG_OK;
 }
 
@@ -876,13 +885,8 @@ int kzg_quotient(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t 
     if (slot < 0) return KZG_ERR_BUSY;
     Slot& s = ctx->slots[slot];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!s.stream) {  // quotient does not need an SRS: make the slot usable on its own
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        for (auto& e : s.ev) HIP_TRY(ctx, hipEventCreate(&e));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-        HIP_TRY(ctx, hipMalloc(&s.d_small, 64 * 4));
-        HIP_TRY(ctx, hipHostMalloc(&s.h_small, 64 * 4));
-    }
+    int rcb = ensure_slot_basics(ctx, s);  // quotient does not need an SRS
+    if (rcb) return rcb;
     bool y_zero = (y[0] | y[1] | y[2] | y[3]) == 0;
     if (n == 0) return y_zero ? KZG_OK : KZG_ERR_CONSTANT_POLY;
     int rc = ensure_poly(ctx, s, n);
@@ -918,13 +922,8 @@ int kzg_evaluate(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t 
     if (slot < 0) return KZG_ERR_BUSY;
     Slot& s = ctx->slots[slot];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (!s.stream) {
-        HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
-        for (auto& e : s.ev) HIP_TRY(ctx, hipEventCreate(&e));
-        HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-        HIP_TRY(ctx, hipMalloc(&s.d_small, 64 * 4));
-        HIP_TRY(ctx, hipHostMalloc(&s.h_small, 64 * 4));
-    }
+    int rcb = ensure_slot_basics(ctx, s);
+    if (rcb) return rcb;
     int rc = ensure_poly(ctx, s, n);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(s.d_stage, coeffs, n * 32, hipMemcpyHostToDevice, s.stream));
