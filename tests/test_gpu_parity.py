@@ -193,6 +193,30 @@ def test_degree_too_high(engines, oracle):
     assert ei.value.status == K.KZG_ERR_DEGREE_TOO_HIGH
 
 
+def test_srs_can_be_replaced_on_a_live_engine(oracle, golden):
+    """Second kzg_srs_generate_g1 / kzg_srs_load_g1 on the same context: new length, new window geometry."""
+    secret = bytes.fromhex(golden["secret_be"])
+    eng = K.Engine(0)
+    try:
+        for n in (100, 5000, 37):
+            eng.srs_generate(secret, n)
+            assert eng.srs_len() == n
+            c = oracle.bench_coefficients(n)
+            rc, want = oracle.commit_pippenger(c, eng.srs_read(0, n), threads=4)
+            assert rc == 0 and eng.commit_limbs(c).compress() == oracle.p1_compress(want), n
+        other = bytes(range(1, 33))
+        srs = oracle.srs_g1(64, other)
+        eng.srs_load(srs)
+        c = oracle.bench_coefficients(64)
+        rc, want = oracle.commit_naive(c, srs)
+        assert rc == 0 and eng.commit_limbs(c).compress() == oracle.p1_compress(want)
+        with pytest.raises(K.KzgError) as ei:
+            eng.wait(0)  # nothing in flight
+        assert ei.value.status == K.KZG_ERR_INVALID_ARG
+    finally:
+        eng.close()
+
+
 def test_commit_before_srs_is_an_error():
     eng = K.Engine(0)
     try:
