@@ -115,10 +115,19 @@ __global__ void __launch_bounds__(kTreeBlock) k_tree_sum(TreeJobs jobs) {
 void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count) {
     TreeJobs jobs;
     jobs.count = count;
+    // One lane per element gives the shortest chain (log2(len) dependent additions) but only ~1/log2(len)
+    // of the lane-steps do work.  With 48 KB of LDS and ~156 VGPRs a CU holds three workgroups, so beyond
+    // 3 x 256 workgroups a second round would start: lanes then pre-add several elements serially.
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < count && i < 4; i++) total += (uint64_t)descs[i].groups * descs[i].len;
+    const uint64_t resident_lanes = 3ull * 256 * kTreeBlock;
+    uint32_t per_lane = 1;
+    while ((total + per_lane - 1) / per_lane > resident_lanes && per_lane < 64) per_lane <<= 1;
     uint32_t blocks = 0;
     for (uint32_t i = 0; i < count && i < 4; i++) {
         uint32_t lpg = 1;
         while (lpg < descs[i].len && lpg < (uint32_t)kTreeBlock) lpg <<= 1;
+        lpg = lpg / per_lane ? lpg / per_lane : 1;
         uint32_t gpb = kTreeBlock / lpg;
         jobs.j[i].in = reinterpret_cast<const uint4*>(descs[i].in);
         jobs.j[i].out = reinterpret_cast<uint4*>(descs[i].out);
