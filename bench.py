@@ -252,6 +252,14 @@ def main():
                 tj = json.load(f)
             if tj.get("batch", 1) == batch:
                 traffic = tj.get("hbm_bytes_per_launch")
+        valu_pmc = {}
+        vpath = os.path.join(ROOT, "profiles", "r01_valu_pmc.json")
+        if world == 1 and degree == DEGREE and batch == 1 and os.path.exists(vpath):
+            with open(vpath) as f:
+                vj = json.load(f)
+            valu_pmc = {"pmc_valu_busy_percent": vj.get("VALUBusy"),
+                        "pmc_valu_lane_utilization_percent": vj.get("VALUUtilization"),
+                        "pmc_source": "profiles/r01_valu_pmc.json (tools/prof_valu.sh, same workload)"}
         line = {
             "metric": "g1_msm_commitments_per_sec_degree_2^20",
             "value": args.steps * batch / elapsed,
@@ -276,7 +284,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "integer-multiply (VALU) bound by construction: see valu"},
             "valu": {"achieved_Tmad_s": tmad, "peak_Tmad_s": VALU_MAD_PEAK_T, "frac": tmad / VALU_MAD_PEAK_T,
-                     "unit": "1e12 v_mad_u64_u32/s", "mixed_additions_per_launch": madds},
+                     "unit": "1e12 v_mad_u64_u32/s", "mixed_additions_per_launch": madds, **valu_pmc},
             "phase_ms": {k: sum(v) / len(v) for k, v in phase_ms.items()},
             "opening_proofs_per_sec": proofs_per_s,
             "quotient_ms": quotient_ms,
