@@ -6,10 +6,19 @@ all-gather of one 144-byte blst_p1 partial sum per rank (RCCL over xGMI when the
 GPU, gloo in the CPU tests), followed by K-1 complete point additions on every rank
 (kzg_g1_sum).  RCCL has no user-defined reduction for curve points, so "reduce" = gather + local
 add; the payload is latency-bound.
+
+Openings shard the same way.  With S[i] = sum_{k>=i} c_k z^(k-i) the quotient is q[j] = S[j+1]
+(reference src/polynomial.rs:168-179) and the proof is sum_j q[j] SRS[j]; rank g owns j in [lo_g, hi_g).
+Its q[j] only need its own coefficients and ONE carry, C_g = S[hi_g], which enters exactly like an extra
+top coefficient: scanning the slice extended by c_ext[len] = C_g yields q[lo_g .. hi_g) and, as its
+"evaluation", S[lo_g] = the carry of rank g-1.  So: every rank evaluates its slice at z (device scan, no
+carry), the K values H_g = sum_{k in slice} c_k z^(k-lo_g) are all-gathered (32 B each), every rank runs
+the K-step recurrence C_{g-1} = H_g + z^(len_g) C_g on the host, then opens its extended slice and the
+partial proofs are combined like partial commitments.  No kernel knows about the sharding.
 """
 import numpy as np
 
-from . import G1Point
+from . import KZG_ERR_CONSTANT_POLY, KZG_ERR_REMAINDER, R_MODULUS, G1Point, KzgError, Scalar, load_library
 
 
 def shard_range(n, rank, world):
@@ -95,4 +104,69 @@ def combine(partials):
 def sharded_commit(engine, coeff_slice_limbs, device=None, group=None):
     """Commit this rank's coefficient slice on its SRS slice and reduce across ranks."""
     partial = engine.commit_limbs(coeff_slice_limbs)
+    return combine(allgather_partials(partial, device=device, group=group))
+
+
+def _allgather_u64(vec, world_group=None, device=None):
+    """All-gathers a small uint64 vector per rank (exchange helper for the opening carries)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(world_group)
+    mine = torch.from_numpy(np.ascontiguousarray(vec, dtype=np.uint64).view(np.int64).copy())
+    if device is not None:
+        mine = mine.to(device)
+    out = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine, group=world_group)
+    return [t.cpu().numpy().view(np.uint64) for t in out]
+
+
+def opening_carries(h_values, lengths, z):
+    """K-step recurrence on the host.  h_values[g] = slice evaluation H_g (int), lengths[g] = slice length.
+    Returns (carries, s_at_slice_start): carries[g] = S[hi_g], s_at_slice_start[g] = S[lo_g]."""
+    k = len(h_values)
+    carries, starts = [0] * k, [0] * k
+    c = 0
+    for g in range(k - 1, -1, -1):
+        carries[g] = c
+        c = (h_values[g] + pow(z, lengths[g], R_MODULUS) * c) % R_MODULUS
+        starts[g] = c
+    return carries, starts
+
+
+def sharded_open_local(engine, coeff_slice_limbs, carry, z, y_at_slice_start):
+    """This rank's partial proof: open the slice extended by the carry as one more top coefficient."""
+    ext = np.concatenate([np.ascontiguousarray(coeff_slice_limbs, dtype=np.uint64).reshape(-1, 4),
+                          Scalar(carry).limbs().reshape(1, 4)])
+    return engine.open_limbs(ext, z, Scalar(y_at_slice_start))
+
+
+def sharded_open(engine, coeff_slice_limbs, z, y, device=None, group=None):
+    """Evaluation::generate_proof (reference src/polynomial.rs:260-269) of a polynomial whose coefficients
+    (and SRS) are range-sharded over the ranks of `group`.  Errors are raised identically on every rank."""
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    sl = np.ascontiguousarray(coeff_slice_limbs, dtype=np.uint64).reshape(-1, 4)
+    h = engine.evaluate_limbs(sl, z) if len(sl) else Scalar(0)
+    first = 1 if rank == 0 else 0  # index 0 of the polynomial is not a "higher" coefficient
+    higher = int(sl[first:].any()) if len(sl) > first else 0
+    c0 = sl[0] if (rank == 0 and len(sl)) else np.zeros(4, dtype=np.uint64)
+    gathered = _allgather_u64(np.concatenate([h.limbs(), [np.uint64(len(sl)), np.uint64(higher)], c0]), group, device)
+    hs = [Scalar.from_limbs(g[:4]).v for g in gathered]
+    lens = [int(g[4]) for g in gathered]
+    any_higher = any(int(g[5]) for g in gathered)
+    c0_limbs = gathered[0][6:10]
+    carries, starts = opening_carries(hs, lens, z.v)
+    lib = load_library()
+    if not any_higher:  # constant polynomial after truncation (src/polynomial.rs:159-167)
+        if Scalar.from_limbs(c0_limbs).v != y.v:
+            raise KzgError(KZG_ERR_CONSTANT_POLY, lib.kzg_strerror(KZG_ERR_CONSTANT_POLY).decode())
+        return G1Point(np.zeros(18, dtype=np.uint64))
+    if starts[0] != y.v:  # P(z) != y (src/polynomial.rs:184-192)
+        raise KzgError(KZG_ERR_REMAINDER, lib.kzg_strerror(KZG_ERR_REMAINDER).decode())
+    if len(sl):
+        partial = sharded_open_local(engine, sl, carries[rank], z, starts[rank])
+    else:
+        partial = G1Point(np.zeros(18, dtype=np.uint64))
     return combine(allgather_partials(partial, device=device, group=group))

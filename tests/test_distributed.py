@@ -65,6 +65,71 @@ def test_two_rank_sharded_commit_over_gloo(golden, n):
     assert got[0] == want and got[1] == want
 
 
+def _open_worker(rank, world, port, n, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+
+    import bigint_twin as T
+    import kzg_poly_commit_exploration_amd as K
+    import oracle_ctypes as O
+    from kzg_poly_commit_exploration_amd import sharding
+
+    class OracleEngine:
+        """Stands in for the GPU engine of this rank (tests only): same two calls, oracle arithmetic."""
+
+        def __init__(self, srs):
+            self.srs = srs
+
+        def evaluate_limbs(self, c, z):
+            return K.Scalar.from_limbs(O.poly_evaluate(c, O.fr_from_int(z.v)))
+
+        def open_limbs(self, c, z, y):
+            rc, pf = O.generate_proof(c, O.fr_from_int(z.v), O.fr_from_int(y.v), self.srs)
+            if rc != 0:
+                raise K.KzgError(rc, "oracle rc %d" % rc)
+            return K.G1Point(pf)
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = sharding.shard_range(n, rank, world)
+        srs = np.stack([O.srs_g1_at(k, T.BENCH_SECRET_BE) for k in range(lo, hi)])
+        c = O.bench_coefficients(n)
+        z = K.Scalar(T.bench_input_point(n - 1))
+        y = K.Scalar.from_limbs(O.poly_evaluate(c, O.fr_from_int(z.v)))
+        proof = sharding.sharded_open(OracleEngine(srs), c[lo:hi], z, y)
+        try:
+            sharding.sharded_open(OracleEngine(srs), c[lo:hi], z, K.Scalar(y.v + 1))
+            wrong = "accepted"
+        except K.KzgError as e:
+            wrong = e.status
+        out_q.put((rank, proof.compress().hex(), wrong))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharded_opening_over_gloo(golden):
+    import torch.multiprocessing as mp
+
+    n = 101
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_open_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = next(b["proof"] for b in golden["bench"] if b["degree"] == n - 1)
+    for _, proof, wrong in got:
+        assert proof == want
+        assert wrong == -3  # KZG_ERR_REMAINDER on every rank
+
+
 def test_shard_ranges_cover_everything():
     sys.path.insert(0, ROOT)
     from kzg_poly_commit_exploration_amd.sharding import shard_range

@@ -380,6 +380,47 @@ def test_sharded_commit_equals_unsharded(engines, oracle, golden):
     assert K.G1Point.sum(parts).compress().hex() == _case(golden, d)["commit"]
 
 
+def test_range_sharded_opening_equals_unsharded(oracle, golden):
+    """Openings sharded by SRS range (sharding.py): K virtual shards on one GPU, carries by the host
+    recurrence, each shard opens its slice extended by the carry; the partial proofs add up to the proof."""
+    from kzg_poly_commit_exploration_amd.sharding import opening_carries, shard_range, sharded_open_local
+
+    secret = bytes.fromhex(golden["secret_be"])
+    for d, k in ((1 << 16, 4), (1000, 3), (5, 8)):
+        n = d + 1
+        c, z, y = _bench_poly(oracle, d) if d != 5 else (oracle.bench_coefficients(6), K.Scalar(77), None)
+        if y is None:
+            y = K.Scalar.from_limbs(oracle.poly_evaluate(c, oracle.fr_from_int(77)))
+        spans = [shard_range(n, r, k) for r in range(k)]
+        engs = []
+        try:
+            hs = []
+            for lo, hi in spans:
+                if hi > lo:
+                    e = K.Engine(0)
+                    e.srs_generate(secret, hi - lo, first=lo)
+                    engs.append(e)
+                    hs.append(e.evaluate_limbs(c[lo:hi], z).v)
+                else:
+                    engs.append(None)
+                    hs.append(0)
+            carries, starts = opening_carries(hs, [hi - lo for lo, hi in spans], z.v)
+            assert starts[0] == y.v  # P(z) reassembled from the slices
+            parts = [sharded_open_local(e, c[lo:hi], carries[r], z, starts[r])
+                     for r, ((lo, hi), e) in enumerate(zip(spans, engs)) if e is not None]
+            got = K.G1Point.sum(parts)
+        finally:
+            for e in engs:
+                if e is not None:
+                    e.close()
+        if d in (1 << 16, 1000):
+            assert got.compress().hex() == _case(golden, d)["proof"], (d, k)
+        else:
+            srs = oracle.srs_g1(n, secret)
+            rc, want = oracle.generate_proof(c, oracle.fr_from_int(z.v), oracle.fr_from_int(y.v), srs)
+            assert rc == 0 and got.compress() == oracle.p1_compress(want)
+
+
 def test_linearity_and_determinism(engines, oracle):
     eng = engines.bench_srs((1 << 16) + 1)
     rnd = random.Random(17)
