@@ -242,7 +242,8 @@ def main():
         # 96 B point + 32 B scalar per term, + 144 B out; one launch = B commitments
         algo_bytes = batch * (n_mine * 128 + 144)
         achieved = algo_bytes / (avg_accum_ms * 1e-3) / 1e9 if avg_accum_ms > 0 else 0.0
-        madds = batch * n_mine * cfg["windows"]    # one mixed addition per (term, window) pair (zero digits aside)
+        refs = phase_ms.pop("references", [])
+        madds = int(sum(refs) / max(1, len(refs)))   # one mixed addition per non-zero scalar digit (counted on the device)
         tmad = madds * MADS_PER_MADD / (avg_accum_ms * 1e-3) / 1e12 if avg_accum_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
@@ -250,7 +251,7 @@ def main():
             # PMC bytes of the same kernel on the same workload, measured off-line by tools/prof_pmc.sh
             with open(tpath) as f:
                 tj = json.load(f)
-            if tj.get("batch", 1) == batch:
+            if tj.get("batch", 1) == batch and tj.get("recoding", "windows") == cfg["recoding"]:
                 traffic = tj.get("hbm_bytes_per_launch")
         valu_pmc = {}
         vpath = os.path.join(ROOT, "profiles", "r01_valu_pmc.json")
@@ -275,8 +276,9 @@ def main():
             "data": "synthetic: reference bench inputs c_i=5^i+10, SRS secret 00..1f, generated on device",
             "config": {"workload": "configs[2]: degree-2^%d commit (G1 MSM, %d terms) on %d x MI355X, SRS-range sharded, "
                                    "%d commitments per step in one batched pass" % (degree.bit_length() - 1, n, world, batch),
-                       "degree": degree, "terms_per_gpu": n_mine, "commitments_per_step": batch, "window_bits": cfg["window_bits"],
-                       "windows": cfg["windows"], "buckets": cfg["buckets"], "stream_slots": slots,
+                       "degree": degree, "terms_per_gpu": n_mine, "commitments_per_step": batch, "recoding": cfg["recoding"],
+                       "digit_bits": cfg["digit_bits"], "table_levels": cfg["table_levels"], "buckets": cfg["buckets"],
+                       "table_gib": round(cfg["table_levels"] * n_mine * 128 / 2**30, 2), "stream_slots": slots,
                        "bit_exact_vs_golden": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

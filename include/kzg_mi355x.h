@@ -175,12 +175,15 @@ typedef struct kzg_kernel_times {
     float reduce_ms;      /* bucket running-sum reduction levels */
     float quotient_ms;    /* open only: scalar-field synthetic division */
     float total_ms;       /* first kernel start -> last kernel end */
+    uint64_t references;  /* non-zero scalar digits = mixed additions of the accumulation kernel (whole batch) */
 } kzg_kernel_times;
 
 int kzg_set_timing(kzg_ctx* ctx, int enabled);
 int kzg_get_times(kzg_ctx* ctx, int slot, kzg_kernel_times* out);
-/* window bits / number of windows / number of buckets chosen for the loaded SRS */
-int kzg_msm_config(const kzg_ctx* ctx, int* window_bits, int* num_windows, size_t* num_buckets);
+/* Scalar recoding chosen for the loaded SRS: recoding 0 = aligned signed windows of digit_bits
+ * (table_levels = number of windows), 1 = width-digit_bits non-adjacent form over a table with one level per
+ * scalar bit (table_levels = 255; chosen when that table fits the free HBM).  Any out pointer may be NULL. */
+int kzg_msm_config(const kzg_ctx* ctx, int* digit_bits, int* table_levels, size_t* num_buckets, int* recoding);
 
 #ifdef __cplusplus
 }

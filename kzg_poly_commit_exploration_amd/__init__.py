@@ -58,11 +58,13 @@ class KzgError(Exception):
 
 class KernelTimes(C.Structure):
     _fields_ = [(n, C.c_float) for n in
-                ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "quotient_ms", "total_ms")]
+                ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "quotient_ms", "total_ms")
+                ] + [("references", C.c_uint64)]
 
 
 def lib_path():
-    return os.path.join(_HERE, "libkzg_mi355x.so")
+    # KZG_MI355X_LIB: another build of the same library (A/B measurements of kernel variants)
+    return os.environ.get("KZG_MI355X_LIB") or os.path.join(_HERE, "libkzg_mi355x.so")
 
 
 _LIB = None
@@ -113,7 +115,7 @@ def load_library():
         "kzg_g1_compress": (i, [vp, vp]),
         "kzg_set_timing": (i, [vp, i]),
         "kzg_get_times": (i, [vp, i, C.POINTER(KernelTimes)]),
-        "kzg_msm_config": (i, [vp, C.POINTER(i), C.POINTER(i), C.POINTER(sz)]),
+        "kzg_msm_config": (i, [vp, C.POINTER(i), C.POINTER(i), C.POINTER(sz), C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)
@@ -315,9 +317,10 @@ class Engine:
         return int(self._lib.kzg_srs_len(self._h))
 
     def msm_config(self):
-        c, w, nb = C.c_int(), C.c_int(), C.c_size_t()
-        _check(self._lib.kzg_msm_config(self._h, C.byref(c), C.byref(w), C.byref(nb)))
-        return {"window_bits": c.value, "windows": w.value, "buckets": nb.value}
+        c, w, nb, rec = C.c_int(), C.c_int(), C.c_size_t(), C.c_int()
+        _check(self._lib.kzg_msm_config(self._h, C.byref(c), C.byref(w), C.byref(nb), C.byref(rec)))
+        return {"recoding": "naf" if rec.value == 1 else "windows", "digit_bits": c.value,
+                "table_levels": w.value, "buckets": nb.value}
 
     # -- hot path, host buffers --
     def commit_limbs(self, coeffs):

@@ -97,10 +97,11 @@ struct kzg_ctx {
     // the light sort / reduction kernels of the other slots run beside it on the slots' own streams.
     hipStream_t heavy_stream = nullptr;
     bool serialize_accum = true;   // KZG_SERIALIZE_ACCUM=0 lets accumulation kernels of different slots overlap
-    // LDS reserved per accumulation workgroup (KZG_ACCUM_LDS_KB overrides): 41 KB admits three workgroups
-    // per CU = 3 waves/SIMD (the grid is sized to 3 x 256 x 256 lanes, one resident round), which leaves
-    // one wave slot and 128 VGPRs per SIMD to the light kernels of the other slots (sort, quotient).
-    // Measured against full occupancy (0 KB, 262144 lanes): commitments/s -1 %, opening proofs/s +6 %.
+    // LDS reserved per accumulation workgroup (KZG_ACCUM_LDS_KB overrides): 41 KB caps the kernel at three
+    // workgroups per CU whatever its register count.  The shipped build (lazily reduced field, 206 VGPRs) is
+    // register-limited to two workgroups per CU anyway, which leaves two wave slots and ~100 VGPRs per SIMD to
+    // the light kernels of the other slots (sort, quotient); the reservation only matters for builds under
+    // 170 VGPRs (a 168-VGPR build with 10 spilled registers measured 9 % slower with three slots in flight).
     uint32_t accum_lds_bytes = 41u * 1024u;
     bool slots_ready = false;
     bool timing = false;
@@ -170,7 +171,8 @@ int ensure_poly(kzg_ctx* ctx, Slot& s, size_t n) {
 // reduction plan: depends only on the bucket count
 void plan_reduce(kzg_ctx* ctx) {
     ReducePlan P;
-    uint32_t bits = ctx->cfg.c - 1;
+    uint32_t bits = 0;  // log2(buckets)
+    while ((1u << bits) < ctx->cfg.nb) bits++;
     P.lo_bits = bits / 2;
     P.hi_bits = bits - P.lo_bits;
     P.row_lo = P.hi_bits / 2;
@@ -193,7 +195,7 @@ int setup_slots(kzg_ctx* ctx) {
     const MsmConfig cfg = ctx->cfg;
     if (ctx->max_batch > sort_max_batch(cfg)) ctx->max_batch = sort_max_batch(cfg);
     const size_t B = ctx->max_batch;
-    const size_t pairs = (size_t)cfg.W * ctx->n * B;
+    const size_t pairs = (size_t)cfg.max_digits * ctx->n * B;
     for (int i = 0; i < kNumSlots; i++) {
         Slot& s = ctx->slots[i];
         {
@@ -223,13 +225,13 @@ int setup_slots(kzg_ctx* ctx) {
     return KZG_OK;
 }
 
-// builds windows 1..W-1 of the table from window 0 (already in d_table[0..n))
+// builds levels 1..W-1 of the table from level 0 (already in d_table[0..n))
 int build_tables(kzg_ctx* ctx, hipStream_t st, void* d_xyzz_tmp, void* d_prefix) {
     const size_t n = ctx->n;
     for (uint32_t j = 1; j < ctx->cfg.W; j++) {
         char* prev = (char*)ctx->d_table + (size_t)(j - 1) * n * kAffineBytes;
         char* next = (char*)ctx->d_table + (size_t)j * n * kAffineBytes;
-        launch_table_window(st, prev, (uint32_t)n, ctx->cfg.c, d_xyzz_tmp, d_prefix, next);
+        launch_table_window(st, prev, (uint32_t)n, ctx->cfg.level_bits, d_xyzz_tmp, d_prefix, next);
     }
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -253,7 +255,13 @@ int srs_prepare(kzg_ctx* ctx, size_t n) {
         ctx->d_table = nullptr;
     }
     ctx->n = 0;
-    MsmConfig cfg = choose_msm_config(n);
+    // The opt-in NAF recoding wants a 255-level table (engine.h); it may take up to 60 % of the HBM that is free
+    // now (KZG_TABLE_GB overrides), otherwise the windowed recoding with its ~15 levels is used.
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(ctx, hipMemGetInfo(&free_b, &total_b));
+    size_t budget = (size_t)((double)free_b * 0.6);
+    if (const char* v = std::getenv("KZG_TABLE_GB")) budget = (size_t)(std::strtod(v, nullptr) * 1073741824.0);
+    MsmConfig cfg = choose_msm_config(n, budget);
     if ((size_t)cfg.W * n >= 0x80000000ull) return KZG_ERR_INVALID_ARG;  // table index must fit 31 bits
     ctx->cfg = cfg;
     HIP_TRY(ctx, hipMalloc(&ctx->d_table, (size_t)cfg.W * n * kAffineBytes));
@@ -273,8 +281,7 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 1], st));
         HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 2], st));
     }
-    const uint64_t max_refs = (uint64_t)n * cfg.W * batch;
-    const uint32_t L = accumulate_segment_len(max_refs);
+    const uint32_t lanes = accumulate_lanes((uint64_t)n * cfg.max_digits * batch);
     HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)nbt * kXyzzBytes, st));  // zero = infinity
     HIP_TRY(ctx, hipMemsetAsync(s.d_small + 25, 0, 4, st));
     // hand over to the shared accumulation stream and back
@@ -284,14 +291,15 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         HIP_TRY(ctx, hipStreamWaitEvent(hs, s.sorted_ev, 0));
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 3], hs));
-    launch_bucket_accumulate(hs, ctx->d_table, s.d_sorted, s.d_offs, nbt, L, max_refs, s.d_buckets, s.d_part_a,
-                             s.d_part_b, ctx->accum_lds_bytes);
+    launch_bucket_accumulate(hs, ctx->d_table, s.d_sorted, s.d_offs, nbt, lanes, s.d_buckets, s.d_part_a, s.d_part_b,
+                             ctx->accum_lds_bytes);
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], hs));
     if (ctx->serialize_accum) {
         HIP_TRY(ctx, hipEventRecord(s.accum_ev, hs));
         HIP_TRY(ctx, hipStreamWaitEvent(st, s.accum_ev, 0));
     }
-    launch_bucket_finalize(st, s.d_offs, nbt, L, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_list, s.d_small + 25);
+    launch_bucket_finalize(st, s.d_offs, nbt, lanes, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_list, s.d_small + 25);
+    HIP_TRY(ctx, hipMemcpyAsync(s.d_small + 26, s.d_offs + nbt, 4, hipMemcpyDeviceToDevice, st));  // references
     // reduction: Row / Col tree sums of every polynomial's bucket matrix, each split once more.
     // Vectors are polynomial-major ([p][index]); the final buffer holds four sections [p][len_k].
     {
@@ -342,8 +350,10 @@ hf::P1 finish_msm(const kzg_ctx* ctx, const Slot& s, uint32_t p = 0, uint32_t ba
     // W(Row) = 2^row_lo * wsum(R2row) + wsum(C2row);  W(Col) likewise
     hf::P1 w_row = hf::p1_add(host_shift(host_wsum(at(P.off_r2row, rh), rh), P.row_lo), host_wsum(at(P.off_c2row, rl), rl));
     hf::P1 w_col = hf::p1_add(host_shift(host_wsum(at(P.off_r2col, ch), ch), P.col_lo), host_wsum(at(P.off_c2col, cl), cl));
-    // sum_b b B_b = C * W(Row) + W(Col);  sum_b B_b = sum of R2row
+    // sum_b b B_b = C * W(Row) + W(Col);  sum_b B_b = sum of R2row.
+    // Bucket b weighs b + 1 (windows: digit magnitude) or 2b + 1 (NAF: odd digits only).
     hf::P1 total = hf::p1_add(host_shift(w_row, P.lo_bits), w_col);
+    if (ctx->cfg.recode == kRecodeNaf) total = hf::p1_double(total);
     const uint64_t* r2 = at(P.off_r2row, rh);
     for (uint32_t k = 0; k < rh; k++) total = hf::p1_add(total, hf::p1_from_xyzz(r2 + (size_t)k * kXyzzWords64));
     return hf::p1_normalize(total);
@@ -430,11 +440,12 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
 size_t kzg_srs_len(const kzg_ctx* ctx) { return ctx ? ctx->n : 0; }
 int kzg_num_slots(const kzg_ctx*) { return kNumSlots; }
 
-int kzg_msm_config(const kzg_ctx* ctx, int* window_bits, int* num_windows, size_t* num_buckets) {
+int kzg_msm_config(const kzg_ctx* ctx, int* digit_bits, int* table_levels, size_t* num_buckets, int* recoding) {
     if (!ctx || !ctx->n) return KZG_ERR_NO_SRS;
-    if (window_bits) *window_bits = (int)ctx->cfg.c;
-    if (num_windows) *num_windows = (int)ctx->cfg.W;
+    if (digit_bits) *digit_bits = (int)ctx->cfg.c;
+    if (table_levels) *table_levels = (int)ctx->cfg.W;
     if (num_buckets) *num_buckets = ctx->cfg.nb;
+    if (recoding) *recoding = (int)ctx->cfg.recode;
     return KZG_OK;
 }
 
@@ -620,6 +631,7 @@ static int wait_locked(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
         hipEventElapsedTime(&ms, s.ev[2], s.ev[3]); s.times.scatter_ms = ms;
         hipEventElapsedTime(&ms, s.ev[3], s.ev[4]); s.times.accumulate_ms = ms;
         hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;
+        s.times.references = s.h_small[26];
         if (s.has_quotient) {
             hipEventElapsedTime(&ms, s.ev[6], s.ev[7]); s.times.quotient_ms = ms;
             hipEventElapsedTime(&ms, s.ev[6], s.ev[5]); s.times.total_ms = ms;
@@ -712,6 +724,7 @@ int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
         (void)hipEventElapsedTime(&ms, s.ev[2], s.ev[3]); s.times.scatter_ms = ms;
         (void)hipEventElapsedTime(&ms, s.ev[3], s.ev[4]); s.times.accumulate_ms = ms;
         (void)hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;
+        s.times.references = s.h_small[26];
         (void)hipEventElapsedTime(&ms, s.ev[0], s.ev[5]); s.times.total_ms = ms;
     }
     // host tails of the batch in parallel (each is ~150 point operations and one inversion)
@@ -777,6 +790,7 @@ int kzg_open_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n
     rc = enqueue_msm(ctx, s, s.d_q, 1, nq, 0, (uint32_t)batch, nq);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(s.h_bsmall, s.d_bsmall, batch * 32 * 4, hipMemcpyDeviceToHost, s.stream));
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
     s.kind = SLOT_OPEN;
     return KZG_OK;
@@ -798,6 +812,7 @@ int kzg_wait_open_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, int* statuses
         (void)hipEventElapsedTime(&ms, s.ev[0], s.ev[1]); s.times.digits_ms = ms;
         (void)hipEventElapsedTime(&ms, s.ev[3], s.ev[4]); s.times.accumulate_ms = ms;
         (void)hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;
+        s.times.references = s.h_small[26];
         (void)hipEventElapsedTime(&ms, s.ev[6], s.ev[5]); s.times.total_ms = ms;
     }
     const uint32_t B = s.job_batch;

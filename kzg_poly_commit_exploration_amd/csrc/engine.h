@@ -11,40 +11,63 @@ namespace kzg {
 // (96 bytes of payload), (0,0) = infinity, padded to a 128-byte record so that every random gather of
 // the accumulation kernel touches exactly one 128-byte line (at 96 B a record straddles 1.5 lines on
 // average and the kernel fetched 2x its payload; PMC figures in DESIGN.md).  Table layout:
-// window-major, T[j * n + i] = 2^(c*j) * SRS[i]  (j < W), so window 0 is the SRS itself.
+// level-major, T[j * n + i] = 2^(level_bits*j) * SRS[i]  (j < W), so level 0 is the SRS itself.
 constexpr size_t kAffineBytes = 128;
 constexpr size_t kAffineU4 = kAffineBytes / 16;  // record stride in uint4 units
 // One XYZZ accumulator in HBM: X, Y, ZZ, ZZZ, 4 x 12 u32 = 192 bytes.
 constexpr size_t kXyzzBytes = 192;
 constexpr size_t kXyzzWords64 = 24;
 
+// Two scalar recodings share every kernel after the digit loop:
+//   kRecodeWindows  aligned signed windows of c bits: W = ceil(255/c) digits per scalar, one table level per
+//                   window (level_bits = c), digit magnitude 1 .. 2^(c-1) -> 2^(c-1) buckets of weight b+1.
+//   kRecodeNaf      width-c non-adjacent form: digits are odd, |d| < 2^(c-1), at most one per c consecutive
+//                   bits and on average one per c+1 bits (vs one per c-1 for the same bucket count with
+//                   windows: ~11 % fewer mixed additions), but a digit can start at ANY bit, so the table
+//                   carries one level per scalar bit (W = 255, level_bits = 1): 255 x n x 128 B, 34 GB at
+//                   2^20 points, which the 288 GB of HBM3E hold easily.  2^(c-2) buckets of weight 2b+1.
+//                   Opt-in (KZG_MSM_RECODE=naf): bit-exact, but on MI355X the fewer additions are eaten by
+//                   address-translation misses of the gathers over the larger table (msm_sort.hip).
+enum : uint32_t { kRecodeWindows = 0, kRecodeNaf = 1 };
 struct MsmConfig {
-    uint32_t c;   // window bits
-    uint32_t W;   // windows = ceil(256 / c)
-    uint32_t nb;  // buckets = 2^(c-1)  (signed digits, magnitude 1 .. 2^(c-1))
+    uint32_t recode;      // kRecodeWindows | kRecodeNaf
+    uint32_t c;           // digit width in bits
+    uint32_t W;           // table levels
+    uint32_t level_bits;  // doublings between consecutive table levels
+    uint32_t nb;          // buckets per polynomial (power of two)
+    uint32_t max_digits;  // bound on the non-zero digits of one scalar
 };
 
-MsmConfig choose_msm_config(size_t n_points);
+// table_budget_bytes: what the table may occupy (the NAF recoding is refused when its table does not fit)
+MsmConfig choose_msm_config(size_t n_points, size_t table_budget_bytes);
+
+// Segment length of the bucket accumulation for M sorted references on `lanes` lanes (msm_accum.hip): computed
+// on the device from the actual M, so that scalars with many zero digits still fill every lane.
+__host__ __device__ inline uint32_t accumulate_seg_len(uint32_t M, uint32_t lanes) {
+    uint32_t L = (M + lanes - 1) / lanes;
+    return L < 8u ? 8u : L;
+}
 
 // ---- msm_kernels.hip --------------------------------------------------------------------
 // scalar recoding + two-level LDS counting sort of `batch` polynomials of n terms at once (polynomial p
 // at d_scalars + p * stride scalars; its buckets are [p * nb, (p+1) * nb)): fills
 // d_offs[0 .. batch*nb] (last = number of references) and d_sorted (bucket-major table references,
 // index | sign << 31).  d_cnt: sort_count_entries(max_batch, cfg) u32; d_block_sums: 1024 u32;
-// d_pairs: batch * n * W u64.  batch <= sort_max_batch(cfg).
+// d_pairs: batch * n * max_digits u64.  batch <= sort_max_batch(cfg).
 uint32_t sort_count_entries(uint32_t max_batch, MsmConfig cfg);
 uint32_t sort_max_batch(MsmConfig cfg);
 void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n, uint32_t batch,
                         uint64_t stride, uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt,
                         uint32_t* d_block_sums, uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted);
 // bucket accumulation (dominant kernel): one lane per segment of L sorted references
-constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on ceil(max_refs / accumulate_segment_len(max_refs))
-uint32_t accumulate_segment_len(uint64_t max_refs);
+constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on accumulate_lanes()
+// lanes (= segments) for at most max_refs references; a multiple of the workgroup size
+uint32_t accumulate_lanes(uint64_t max_refs);
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
-                              uint32_t nb, uint32_t L, uint64_t max_refs, void* d_buckets /* pre-zeroed */,
+                              uint32_t nb, uint32_t lanes, void* d_buckets /* pre-zeroed */,
                               void* d_part_a, void* d_part_b, uint32_t lds_reserve_bytes);
 // adds the head / tail partials of buckets that span several segments (serial, or tree for long spans)
-void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t L, const void* d_part_a,
+void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t lanes, const void* d_part_a,
                             const void* d_part_b, void* d_buckets, uint32_t* d_heavy_list,
                             uint32_t* d_heavy_count /* pre-zeroed */);
 // out[g] = sum_{q<len} in[g*gstride + q*estride], XYZZ records: log-depth tree per group;
@@ -64,7 +87,7 @@ void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count);
 // blst_p1 Jacobian (host layout, strided) already copied to d_jac (n x 144 B contiguous) -> affine
 void launch_jacobian_to_affine(hipStream_t s, const void* d_jac, uint32_t n, void* d_affine_out,
                                void* d_prefix_tmp);
-// table window j from window j-1:  T[j][i] = 2^c * T[j-1][i]
+// table level j from level j-1:  T[j][i] = 2^c * T[j-1][i]
 void launch_table_window(hipStream_t s, const void* d_prev_affine, uint32_t n, uint32_t c,
                          void* d_xyzz_tmp, void* d_prefix_tmp, void* d_next_affine);
 // fixed-base trusted setup: out[i] = [s^(first+i)] G1, affine

@@ -76,18 +76,20 @@ KZG_DEV uint32_t bucket_of(const uint32_t* __restrict__ offs, uint32_t nb, uint3
     return lo;
 }
 
-// One lane per segment [lane*L, lane*L + L) of the sorted references.
+// One lane per segment [lane*L, lane*L + L) of the M sorted references, L = accumulate_seg_len(M, lanes):
+// the launch only fixes the number of lanes, the segment length follows the actual number of non-zero digits.
 //   complete runs   -> buckets[b]
 //   run touching the segment start (bucket continues from the previous lane, or the whole segment
 //   lies inside one bucket) -> part_a[lane];  run touching only the segment end -> part_b[lane]
 __global__ void __launch_bounds__(kAccumBlock) k_bucket_accumulate(const uint4* __restrict__ table,
                                                                   const uint32_t* __restrict__ sorted,
                                                                   const uint32_t* __restrict__ offs, uint32_t nb,
-                                                                  uint32_t L, uint4* __restrict__ buckets,
+                                                                  uint32_t lanes, uint4* __restrict__ buckets,
                                                                   uint4* __restrict__ part_a,
                                                                   uint4* __restrict__ part_b) {
     const uint32_t lane = blockIdx.x * kAccumBlock + threadIdx.x;
     const uint32_t M = offs[nb];
+    const uint32_t L = accumulate_seg_len(M, lanes);
     const uint64_t start64 = (uint64_t)lane * L;
     if (start64 >= M) return;
     const uint32_t start = (uint32_t)start64;
@@ -98,7 +100,8 @@ __global__ void __launch_bounds__(kAccumBlock) k_bucket_accumulate(const uint4* 
     uint32_t run_start = start;
     XYZZ acc = XYZZ::inf();
     // software pipeline: the gather of reference e+1 is issued before the ~2900 multiply-adds of e
-    // (+1.5 % measured; the kernel has the registers to spare at 3 waves/SIMD)
+    // (+1.5 % measured).  Two points in flight, with the reference itself loaded an iteration earlier, measured
+    // 2 % SLOWER (232 instead of 206 VGPRs, same 2 waves/SIMD): the gather latency is already covered.
     u32 ref = sorted[start];
     Affine p = load_affine(table, ref & 0x7fffffffu);
     for (uint32_t e = start; e < end; e++) {
@@ -130,27 +133,28 @@ __global__ void __launch_bounds__(kAccumBlock) k_bucket_accumulate(const uint4* 
     store_xyzz(dst, acc);
 }
 
-uint32_t accumulate_segment_len(uint64_t max_refs) {
-    // one segment per resident lane of the chip (256 CUs x 4 SIMDs x 3 waves x 64 lanes, see the LDS
-    // reservation in api.hip): the whole grid is resident at once; a second, partially filled round of
-    // workgroups would cost up to 2x.  KZG_ACCUM_LANES overrides for experiments.
-    static const uint64_t lanes = [] {
+uint32_t accumulate_lanes(uint64_t max_refs) {
+    // 196608 segments = 768 workgroups.  At 206 VGPRs two workgroups are resident per CU (512 at once); the
+    // last 256 start as the first ones retire and then run with the SIMDs half empty, i.e. faster per wave.
+    // Measured at 2^20 terms: 196608 lanes 3.16 ms, 131072 lanes (exactly one resident round) 3.21 ms,
+    // 262144 lanes slower again.  KZG_ACCUM_LANES overrides for experiments.
+    static const uint64_t target = [] {
         const char* v = std::getenv("KZG_ACCUM_LANES");
         uint64_t l = v ? std::strtoull(v, nullptr, 10) : 196608ull;
         return l < 64 ? 262144ull : (l > 262144ull ? 262144ull : l);
     }();
-    uint64_t L = (max_refs + lanes - 1) / lanes;
-    if (L < 8) L = 8;
-    return (uint32_t)L;
+    uint64_t lanes = (max_refs + 7) / 8;  // segments are at least 8 references long
+    if (lanes > target) lanes = target;
+    lanes = (lanes + kAccumBlock - 1) / kAccumBlock * kAccumBlock;
+    return (uint32_t)lanes;
 }
 
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
-                              uint32_t nb, uint32_t L, uint64_t max_refs, void* d_buckets, void* d_part_a,
-                              void* d_part_b, uint32_t lds_reserve_bytes) {
-    uint32_t lanes = (uint32_t)((max_refs + L - 1) / L);
+                              uint32_t nb, uint32_t lanes, void* d_buckets, void* d_part_a, void* d_part_b,
+                              uint32_t lds_reserve_bytes) {
     if (!lanes) return;
-    hipLaunchKernelGGL(k_bucket_accumulate, dim3((lanes + kAccumBlock - 1) / kAccumBlock), dim3(kAccumBlock),
-                       lds_reserve_bytes, s, reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb, L,
+    hipLaunchKernelGGL(k_bucket_accumulate, dim3(lanes / kAccumBlock), dim3(kAccumBlock), lds_reserve_bytes, s,
+                       reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb, lanes,
                        reinterpret_cast<uint4*>(d_buckets), reinterpret_cast<uint4*>(d_part_a),
                        reinterpret_cast<uint4*>(d_part_b));
 }

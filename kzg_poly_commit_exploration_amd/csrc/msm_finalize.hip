@@ -47,7 +47,7 @@ KZG_DEV XYZZ load_xyzz(const uint4* __restrict__ in) {
 // Buckets that span several segments: add up their partials (first segment's tail or whole, whole
 // middle segments, last segment's head).  One lane per bucket; very long spans (skewed scalars) are
 // queued for k_bucket_heavy.
-__global__ void __launch_bounds__(64) k_bucket_finalize(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t L,
+__global__ void __launch_bounds__(64) k_bucket_finalize(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t lanes,
                                                         const uint4* __restrict__ part_a,
                                                         const uint4* __restrict__ part_b,
                                                         uint4* __restrict__ buckets,
@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(64) k_bucket_finalize(const uint32_t* __restri
                                                         uint32_t* __restrict__ heavy_count) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb) return;
+    const uint32_t L = accumulate_seg_len(offs[nb], lanes);
     uint32_t s = offs[b], e = offs[b + 1];
     if (s == e) return;  // empty bucket: stays at infinity (buffer pre-zeroed)
     uint32_t l_lo = s / L, l_hi = (e - 1) / L;
@@ -74,7 +75,7 @@ __global__ void __launch_bounds__(64) k_bucket_finalize(const uint32_t* __restri
 }
 
 // One workgroup per queued bucket: strided partial sums, then a tree in LDS.
-__global__ void __launch_bounds__(kHeavyBlock) k_bucket_heavy(const uint32_t* __restrict__ offs, uint32_t L,
+__global__ void __launch_bounds__(kHeavyBlock) k_bucket_heavy(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t lanes,
                                                               const uint4* __restrict__ part_a,
                                                               const uint4* __restrict__ part_b,
                                                               uint4* __restrict__ buckets,
@@ -83,6 +84,7 @@ __global__ void __launch_bounds__(kHeavyBlock) k_bucket_heavy(const uint32_t* __
     __shared__ u32 lds[48 * kHeavyBlock];
     const int t = threadIdx.x;
     const uint32_t count = *heavy_count;
+    const uint32_t L = accumulate_seg_len(offs[nb], lanes);
     for (uint32_t h = blockIdx.x; h < count; h += gridDim.x) {
         uint32_t b = heavy_list[h];
         uint32_t s = offs[b], e = offs[b + 1];
@@ -118,12 +120,12 @@ __global__ void __launch_bounds__(kHeavyBlock) k_bucket_heavy(const uint32_t* __
     }
 }
 
-void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t L, const void* d_part_a,
+void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t lanes, const void* d_part_a,
                             const void* d_part_b, void* d_buckets, uint32_t* d_heavy_list, uint32_t* d_heavy_count) {
-    hipLaunchKernelGGL(k_bucket_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, d_offs, nb, L,
+    hipLaunchKernelGGL(k_bucket_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, d_offs, nb, lanes,
                        reinterpret_cast<const uint4*>(d_part_a), reinterpret_cast<const uint4*>(d_part_b),
                        reinterpret_cast<uint4*>(d_buckets), d_heavy_list, d_heavy_count);
-    hipLaunchKernelGGL(k_bucket_heavy, dim3(kHeavyGrid), dim3(kHeavyBlock), 0, s, d_offs, L,
+    hipLaunchKernelGGL(k_bucket_heavy, dim3(kHeavyGrid), dim3(kHeavyBlock), 0, s, d_offs, nb, lanes,
                        reinterpret_cast<const uint4*>(d_part_a), reinterpret_cast<const uint4*>(d_part_b),
                        reinterpret_cast<uint4*>(d_buckets), d_heavy_list, d_heavy_count);
 }

@@ -6,30 +6,62 @@
 // HBM traffic per commitment of n terms, W windows: scalars read twice (2 x 32 B x n), pairs written
 // once and read twice (3 x 8 B x n x W), references written (4 B x n x W).  Integer / byte work bound
 // by LDS atomics and scattered 4..8-byte stores, not by arithmetic.
+#include <cstdlib>
+#include <cstring>
+
 #include "engine.h"
 #include "field.hip.h"
 
 namespace kzg {
 
-MsmConfig choose_msm_config(size_t n) {
-    // Scalars are first folded to |k| <= (r-1)/2 < 2^254 (sign moved onto the point), so
-    // W = ceil(255 / c) signed windows never carry out of the top.  c minimises
-    //     n * W  (mixed additions)  +  8 * 2^(c-1)  (bucket finalisation + reduction, weighted for
-    // the latency of the reduction levels): 17 bits / 15 windows / 65536 buckets at 2^20 points.
+static uint32_t ilog2(uint32_t v) {
+    uint32_t b = 0;
+    while ((1u << b) < v) b++;
+    return b;
+}
+
+MsmConfig choose_msm_config(size_t n, size_t table_budget_bytes) {
+    // Scalars are first folded to |k| <= (r-1)/2 < 2^254 (sign moved onto the point), so signed digits never
+    // carry out of bit 254.  The digit width c minimises
+    //     n * (digits per scalar)  (mixed additions)  +  8 * buckets  (bucket finalisation + reduction,
+    // weighted for the latency of the reduction levels).
+    //   windows: ceil(255/c) digits, 2^(c-1) buckets -> 17 bits / 15 windows / 65536 buckets at 2^20 points
+    //   NAF:     255/(c+1) digits on average, 2^(c-2) buckets -> 19 bits / 13.1 digits / 131072 buckets
+    // The NAF recoding is opt-in (KZG_MSM_RECODE=naf, and its 255-level table must fit the budget): measured on
+    // MI355X at 2^20 points it saves 12.8 % of the mixed additions but each one costs 12 % more, because random
+    // gathers over a 34 GB table miss the per-CU translation cache 74 % of the time instead of 0.5 % over the
+    // 2 GB window table (TCP_UTCL1_TRANSLATION_MISS).  KZG_MSM_C=<bits> overrides c.
+    const char* force_mode = std::getenv("KZG_MSM_RECODE");
+    const char* force_c = std::getenv("KZG_MSM_C");
+    const uint32_t fc = force_c ? (uint32_t)std::strtoul(force_c, nullptr, 10) : 0u;
+    const bool naf = force_mode && !std::strcmp(force_mode, "naf") && n * 255ull < 0x80000000ull &&
+                     (double)n * 255.0 * (double)kAffineBytes <= (double)table_budget_bytes;
     uint32_t best_c = 8;
+    const uint32_t best_mode = naf ? kRecodeNaf : kRecodeWindows;
     double best = 1e300;
-    for (uint32_t c = 8; c <= 20; c++) {
-        uint32_t W = (255 + c - 1) / c;
-        double cost = (double)n * W + 8.0 * (double)(1u << (c - 1));
+    for (uint32_t c = 8; c <= (naf ? 21u : 20u); c++) {
+        if (fc >= 8 && fc <= (naf ? 21u : 20u) && c != fc) continue;
+        double cost = naf ? (double)n * (255.0 / (c + 1) + 0.5) + 8.0 * (double)(1u << (c - 2))
+                          : (double)n * ((255 + c - 1) / c) + 8.0 * (double)(1u << (c - 1));
         if (cost < best) {
             best = cost;
             best_c = c;
         }
     }
     MsmConfig cfg;
+    cfg.recode = best_mode;
     cfg.c = best_c;
-    cfg.W = (255 + best_c - 1) / best_c;
-    cfg.nb = 1u << (best_c - 1);
+    if (best_mode == kRecodeNaf) {
+        cfg.W = 255;
+        cfg.level_bits = 1;
+        cfg.nb = 1u << (best_c - 2);
+        cfg.max_digits = (255 + best_c - 1) / best_c + 1;  // non-zero digits are at least c bits apart
+    } else {
+        cfg.W = (255 + best_c - 1) / best_c;
+        cfg.level_bits = best_c;
+        cfg.nb = 1u << (best_c - 1);
+        cfg.max_digits = cfg.W;
+    }
     return cfg;
 }
 
@@ -67,9 +99,9 @@ KZG_DEV bool load_scalar(const uint32_t* d_scalars, uint64_t i, int is_mont, u32
 
 // Signed window recoding, low window first: digit in [-2^(c-1)+1, 2^(c-1)], carry into the next
 // window.  |k| < 2^254 and W * c >= 255, so the top window absorbs the last carry.
-// f(j, magnitude (>0), negative)
+// f(table level, bucket, negative)
 template <class F>
-KZG_DEV void for_each_digit(u32 k[8], uint32_t c, uint32_t W, F&& f) {
+KZG_DEV void for_each_window_digit(u32 k[8], uint32_t c, uint32_t W, F&& f) {
     const u32 mask = (1u << c) - 1u;
     const u32 half = 1u << (c - 1);
     u32 carry = 0;
@@ -82,8 +114,50 @@ KZG_DEV void for_each_digit(u32 k[8], uint32_t c, uint32_t W, F&& f) {
         bool neg = v > half;
         u32 mag = neg ? (mask + 1u - v) : v;
         carry = neg ? 1u : 0u;
-        if (mag) f(j, mag, neg);
+        if (mag) f(j, mag - 1u, neg);
     }
+}
+
+// Width-c non-adjacent form, low bit first, without ever shifting the scalar: K' = (k >> pos) + carry is the
+// value still to encode.  K' even -> next bit (the carry is unchanged: bit == carry).  K' odd -> the digit is
+// v = (c bits of k at pos) + carry (no overflow: an odd K' means bit0 + carry == 1), taken as v - 2^c when
+// v > 2^(c-1) (carry 1), and the next c-1 digits are zero.  Words are walked by an unrolled loop so that the
+// scalar stays in registers; zero digits are skipped with one ffs per run.  |k| < 2^254 keeps the last digit at
+// bit <= 254.  Digits are odd: bucket (|d| - 1) / 2, weight 2 * bucket + 1.
+template <class F>
+KZG_DEV void for_each_naf_digit(const u32 k[8], uint32_t c, F&& f) {
+    const u32 mask = (1u << c) - 1u;
+    const u32 half = 1u << (c - 1);
+    u32 carry = 0;
+    uint32_t p = 0;  // bit offset inside word t (can exceed 32 after a digit)
+#pragma unroll
+    for (int t = 0; t < 8; t++) {
+        const uint64_t win = ((uint64_t)(t < 7 ? k[t + 1] : 0u) << 32) | k[t];
+        while (p < 32) {
+            u32 x = (u32)(win >> p);
+            if (carry) x = ~x;
+            // first position at or after p (inside this word) where bit != carry
+            uint32_t z = x ? (uint32_t)__builtin_ctz(x) : 32u;
+            if (z >= 32u - p) {
+                p = 32;
+                break;
+            }
+            p += z;
+            u32 v = ((u32)(win >> p) & mask) + carry;
+            const bool neg = v > half;
+            const u32 mag = neg ? (mask + 1u - v) : v;
+            carry = neg ? 1u : 0u;
+            f(32u * (uint32_t)t + p, (mag - 1u) >> 1, neg);
+            p += c;
+        }
+        p -= 32;
+    }
+}
+
+template <class F>
+KZG_DEV void for_each_digit(u32 k[8], MsmConfig cfg, F&& f) {
+    if (cfg.recode == kRecodeNaf) for_each_naf_digit(k, cfg.c, f);
+    else for_each_window_digit(k, cfg.c, cfg.W, f);
 }
 
 // ---- two-level counting sort of the (scalar, window) pairs by bucket -------------------------
@@ -109,6 +183,11 @@ struct SortGeom {
     uint32_t coarse_bins;  // nb >> fine_bits
 };
 
+static uint32_t sort_fine_bits(MsmConfig cfg) {
+    uint32_t bits = ilog2(cfg.nb);
+    return bits < 8 ? bits : 8;
+}
+
 // `total` scalars (batch * n) into `nb_total` buckets (batch * 2^(c-1): polynomial-major bucket ids)
 static SortGeom sort_geometry(uint64_t total, uint32_t nb_total, MsmConfig cfg) {
     SortGeom g;
@@ -117,20 +196,20 @@ static SortGeom sort_geometry(uint64_t total, uint32_t nb_total, MsmConfig cfg) 
     if (tile < (uint32_t)kSortBlock) tile = kSortBlock;
     g.tile = tile;
     g.tiles = (uint32_t)((total + tile - 1) / tile);
-    g.fine_bits = cfg.c - 1 < 8 ? cfg.c - 1 : 8;
+    g.fine_bits = sort_fine_bits(cfg);
     g.coarse_bins = nb_total >> g.fine_bits;
     return g;
 }
 
 uint32_t sort_max_batch(MsmConfig cfg) {
-    uint32_t fine_bits = cfg.c - 1 < 8 ? cfg.c - 1 : 8;
+    uint32_t fine_bits = sort_fine_bits(cfg);
     uint32_t b = (uint32_t)kMaxCoarse / (cfg.nb >> fine_bits);
     return b < 1 ? 1 : b;
 }
 
 uint32_t sort_count_entries(uint32_t max_batch, MsmConfig cfg) {
     // coarse bins x tiles, tiles bounded by 256 (+1) whatever the length of the commitment
-    uint32_t fine_bits = cfg.c - 1 < 8 ? cfg.c - 1 : 8;
+    uint32_t fine_bits = sort_fine_bits(cfg);
     return ((cfg.nb * max_batch) >> fine_bits) * 257u;
 }
 
@@ -144,7 +223,7 @@ struct BatchGeom {
 };
 
 __global__ void __launch_bounds__(kSortBlock) k_sort_count(const uint32_t* __restrict__ d_scalars, int is_mont,
-                                                           BatchGeom bg, uint32_t c, uint32_t W, uint32_t tile,
+                                                           BatchGeom bg, MsmConfig cfg, uint32_t tile,
                                                            uint32_t tiles, uint32_t fine_bits, uint32_t coarse_bins,
                                                            uint32_t* __restrict__ d_cnt) {
     __shared__ u32 s_hist[kMaxCoarse];
@@ -160,14 +239,14 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_count(const uint32_t* __res
         u32 k[8];
         (void)load_scalar(d_scalars, p * bg.stride + i, is_mont, k);
         const u32 pb = p * bg.nb;
-        for_each_digit(k, c, W, [&](uint32_t, u32 mag, bool) { atomicAdd(&s_hist[(pb + mag - 1) >> fine_bits], 1u); });
+        for_each_digit(k, cfg, [&](uint32_t, u32 bkt, bool) { atomicAdd(&s_hist[(pb + bkt) >> fine_bits], 1u); });
     }
     __syncthreads();
     for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) d_cnt[(size_t)q * tiles + blockIdx.x] = s_hist[q];
 }
 
 __global__ void __launch_bounds__(kSortBlock) k_sort_spread(const uint32_t* __restrict__ d_scalars, int is_mont,
-                                                            BatchGeom bg, uint32_t table_stride, uint32_t c, uint32_t W,
+                                                            BatchGeom bg, uint32_t table_stride, MsmConfig cfg,
                                                             uint32_t tile, uint32_t tiles, uint32_t fine_bits,
                                                             uint32_t coarse_bins, const uint32_t* __restrict__ d_cnt_scanned,
                                                             uint64_t* __restrict__ d_pairs) {
@@ -185,8 +264,8 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_spread(const uint32_t* __re
         u32 k[8];
         const bool flip = load_scalar(d_scalars, p * bg.stride + i, is_mont, k);
         const u32 pb = p * bg.nb;
-        for_each_digit(k, c, W, [&](uint32_t j, u32 mag, bool neg) {
-            u32 b = pb + mag - 1;
+        for_each_digit(k, cfg, [&](uint32_t j, u32 bkt, bool neg) {
+            u32 b = pb + bkt;
             u32 pos = atomicAdd(&s_cur[b >> fine_bits], 1u);
             u32 ref = (j * table_stride + i) | ((neg != flip) ? 0x80000000u : 0u);
             d_pairs[pos] = ((uint64_t)(b & fine_mask) << 32) | ref;
@@ -316,11 +395,11 @@ void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, u
     const uint32_t nb_total = cfg.nb * batch;
     SortGeom g = sort_geometry((uint64_t)n * batch, nb_total, cfg);
     BatchGeom bg{n, batch, stride, cfg.nb};
-    hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, cfg.c, cfg.W, g.tile,
+    hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, cfg, g.tile,
                        g.tiles, g.fine_bits, g.coarse_bins, d_cnt);
     scan_inplace(s, d_cnt, g.coarse_bins * g.tiles, d_block_sums, d_offs + nb_total);  // total refs -> offs[nb_total]
-    hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg.c,
-                       cfg.W, g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_pairs);
+    hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg,
+                       g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_pairs);
     hipLaunchKernelGGL(k_sort_fine, dim3(g.coarse_bins), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
                        g.coarse_bins, d_offs + nb_total, d_offs, d_sorted);
 }

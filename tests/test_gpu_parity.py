@@ -359,6 +359,72 @@ def test_degree_2_16_commit_and_proof(engines, oracle, golden):
     assert rc == 0 and got.compress() == oracle.p1_compress(want)
 
 
+def test_naf_recoding_is_bit_exact(oracle, golden, monkeypatch):
+    """The opt-in width-c NAF recoding (one table level per scalar bit, odd digits, 2^(c-2) buckets of weight
+    2b+1; csrc/msm_sort.hip) must give the same bytes as the default windows: golden 2^16 vectors, skewed and
+    i128-style scalars (whose top digits pile up in a few buckets), a forced digit width."""
+    secret = bytes.fromhex(golden["secret_be"])
+    monkeypatch.setenv("KZG_MSM_RECODE", "naf")
+    d = 1 << 16
+    eng = K.SetupArtifactsGenerator(secret).take(d + 1)
+    try:
+        cfg = eng.msm_config()
+        assert cfg["recoding"] == "naf" and cfg["table_levels"] == 255 and cfg["buckets"] == 1 << (cfg["digit_bits"] - 2)
+        c, z, y = _bench_poly(oracle, d)
+        case = _case(golden, d)
+        assert eng.commit_limbs(c).compress().hex() == case["commit"]
+        assert eng.open_limbs(c, z, y).compress().hex() == case["proof"]
+    finally:
+        eng.close()
+    monkeypatch.setenv("KZG_MSM_C", "9")
+    eng = K.SetupArtifactsGenerator(secret).take(SMALL_N)
+    try:
+        assert eng.msm_config()["digit_bits"] == 9
+        srs = oracle.srs_g1(SMALL_N, secret)
+        rnd = random.Random(7)
+        cases = [[K.R_MODULUS - 1] * SMALL_N, [7] * SMALL_N, [(1 << 254) + 5] * SMALL_N,
+                 [K.Scalar.from_i128(rnd.randrange(-(1 << 127), 1 << 127)).v for _ in range(SMALL_N)],
+                 [rnd.randrange(K.R_MODULUS) for _ in range(SMALL_N)],
+                 [(K.R_MODULUS - 1) // 2, (K.R_MODULUS + 1) // 2, 1, 0, K.R_MODULUS - 2] * 500]
+        for coeffs in cases:
+            c = K.scalars_to_limbs(coeffs)
+            rc, want = oracle.commit_pippenger(c, srs[:len(coeffs)], threads=8)
+            assert rc == 0
+            assert eng.commit_limbs(c).compress() == oracle.p1_compress(want)
+    finally:
+        eng.close()
+    monkeypatch.delenv("KZG_MSM_C")
+    monkeypatch.setenv("KZG_MSM_RECODE", "windows")
+    eng = K.SetupArtifactsGenerator(secret).take(SMALL_N)
+    try:
+        assert eng.msm_config()["recoding"] == "windows"
+    finally:
+        eng.close()
+
+
+def test_zero_heavy_scalars_fill_the_accumulation_lanes(engines, oracle, golden):
+    """The segment length follows the number of non-zero digits counted on the device: i128-style coefficients
+    leave the upper windows empty, a sparse polynomial most of them; results and reference counts must agree."""
+    secret = bytes.fromhex(golden["secret_be"])
+    d = 1 << 16
+    eng = engines.bench_srs(d + 1)
+    srs = eng.srs_read(0, d + 1)
+    rnd = random.Random(99)
+    eng.set_timing(True)
+    try:
+        for coeffs in ([rnd.randrange(1 << 40) for _ in range(d + 1)],
+                       [rnd.randrange(K.R_MODULUS) if i % 64 == 0 else 0 for i in range(d + 1)]):
+            c = K.scalars_to_limbs(coeffs)
+            rc, want = oracle.commit_pippenger(c, srs, threads=8)
+            assert rc == 0
+            assert eng.commit_limbs(c).compress() == oracle.p1_compress(want)
+            refs = max(eng.times(s)["references"] for s in range(eng.num_slots()))
+            levels = eng.msm_config()["table_levels"]
+            assert 0 < refs < (d + 1) * levels // 4
+    finally:
+        eng.set_timing(False)
+
+
 def test_sharded_commit_equals_unsharded(engines, oracle, golden):
     """The multi-GPU decomposition with K virtual shards on one device: rank g holds SRS slice
     [lo, hi) and commits the matching coefficient slice; the sum of partials is the commitment."""

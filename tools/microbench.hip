@@ -274,6 +274,26 @@ __global__ void __launch_bounds__(256) k_gather96(const uint4* __restrict__ tabl
     out[tid] = (u64)acc.x ^ acc.y ^ ((u64)(acc.z ^ acc.w) << 32);
 }
 
+// same with 128-byte records and a footprint parameter: does a window table of tens of GB (one level per
+// scalar bit) still gather at the rate the accumulation kernel needs (~5e9 records/s)?  TLB reach test.
+__global__ void __launch_bounds__(256) k_gather128(const uint4* __restrict__ table, uint32_t records, int iters,
+                                                   u64* out) {
+    uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t state = tid * 2654435761u + 12345u;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (int it = 0; it < iters; it++) {
+        state = state * 1664525u + 1013904223u;
+        uint32_t idx = (uint32_t)(((u64)(state ^ (state >> 15)) * records) >> 32);
+        const uint4* p = table + (size_t)idx * 8;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            uint4 v = p[q];
+            acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+        }
+    }
+    out[tid] = (u64)acc.x ^ acc.y ^ ((u64)(acc.z ^ acc.w) << 32);
+}
+
 template <class K, class... A>
 static double time_kernel(K kern, int grid, int block, int reps, A... args) {
     hipEvent_t e0, e1;
@@ -311,8 +331,32 @@ static int run_gather_calibration() {
     return 0;
 }
 
+static int run_gather_footprints() {
+    const int lanes = 196608, iters = 80;  // the accumulation kernel's shape: 15.7M gathers per launch
+    u64* out;
+    CHECK(hipMalloc(&out, sizeof(u64) * lanes));
+    for (double gib : {2.0, 8.0, 34.0, 137.0}) {
+        size_t bytes = (size_t)(gib * 1073741824.0);
+        uint32_t records = (uint32_t)(bytes / 128);
+        uint4* table;
+        if (hipMalloc(&table, bytes) != hipSuccess) {
+            printf("{\"bench\": \"gather128\", \"footprint_GiB\": %.0f, \"error\": \"hipMalloc failed\"}\n", gib);
+            (void)hipGetLastError();
+            continue;
+        }
+        CHECK(hipMemset(table, 0x5a, bytes));
+        double ms = time_kernel(k_gather128, lanes / 256, 256, 3, (const uint4*)table, records, iters, out);
+        printf("{\"bench\": \"gather128\", \"footprint_GiB\": %.0f, \"gathers\": %d, \"ms\": %.4f, \"Ggather_s\": %.2f}\n", gib,
+               lanes * iters, ms, (double)lanes * iters / ms / 1e6);
+        fflush(stdout);
+        CHECK(hipFree(table));
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc > 1 && !strcmp(argv[1], "gather")) return run_gather_calibration();
+    if (argc > 1 && !strcmp(argv[1], "footprint")) return run_gather_footprints();
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     int cus = prop.multiProcessorCount;
