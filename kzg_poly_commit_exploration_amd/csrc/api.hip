@@ -51,7 +51,7 @@ struct Slot {
     uint32_t* d_sorted = nullptr;
     void* d_buckets = nullptr;
     void *d_part_a = nullptr, *d_part_b = nullptr;  // head / tail partials of the accumulation segments
-    uint32_t* d_heavy_list = nullptr;
+    void* d_heavy_ws = nullptr;   // long-bucket registry + tree buffers of msm_finalize.hip
     void* d_arena = nullptr;     // Row[] then Col[] vectors of the bucket matrix
     void* d_final = nullptr;
     uint64_t* h_final = nullptr;  // pinned
@@ -61,7 +61,7 @@ struct Slot {
     uint32_t* d_q = nullptr;      // quotient
     uint32_t* d_chunk = nullptr;
     uint32_t* d_block = nullptr;
-    uint32_t* d_small = nullptr;  // [0..1] flags, [8..15] P(z), [16..23] c0, [24] tail flag, [25] heavy count
+    uint32_t* d_small = nullptr;  // [0..1] flags, [8..15] P(z), [16..23] c0, [24] tail flag, [26] references
     uint32_t* h_small = nullptr;  // pinned mirror
     uint32_t* d_bsmall = nullptr;  // batched openings: 32 words per polynomial, same layout as d_small[0..31]
     uint32_t* h_bsmall = nullptr;
@@ -79,6 +79,8 @@ struct Slot {
 };
 
 }  // namespace
+
+__global__ void k_reduce_gate(uint32_t* sink);  // defined below
 
 struct kzg_ctx {
     int device = 0;
@@ -103,6 +105,7 @@ struct kzg_ctx {
     // the light kernels of the other slots (sort, quotient); the reservation only matters for builds under
     // 170 VGPRs (a 168-VGPR build with 10 spilled registers measured 9 % slower with three slots in flight).
     uint32_t accum_lds_bytes = 41u * 1024u;
+    uint32_t gate_lds_bytes = 100u * 1024u;  // k_reduce_gate (KZG_REDUCE_GATE_KB overrides, 0 disables)
     bool slots_ready = false;
     bool timing = false;
 };
@@ -130,12 +133,12 @@ struct TmpStream {
 
 void free_slot_msm(Slot& s) {
     hipFree(s.d_cnt); hipFree(s.d_offs); hipFree(s.d_block_sums); hipFree(s.d_pairs); hipFree(s.d_sorted);
-    hipFree(s.d_buckets); hipFree(s.d_part_a); hipFree(s.d_part_b); hipFree(s.d_heavy_list); hipFree(s.d_arena); hipFree(s.d_final);
+    hipFree(s.d_buckets); hipFree(s.d_part_a); hipFree(s.d_part_b); hipFree(s.d_heavy_ws); hipFree(s.d_arena); hipFree(s.d_final);
     if (s.h_final) hipHostFree(s.h_final);
     s.d_cnt = s.d_offs = s.d_block_sums = s.d_sorted = nullptr;
     s.d_pairs = nullptr;
     s.d_buckets = s.d_part_a = s.d_part_b = s.d_arena = s.d_final = nullptr;
-    s.d_heavy_list = nullptr;
+    s.d_heavy_ws = nullptr;
     s.h_final = nullptr;
 }
 void free_slot_poly(Slot& s) {
@@ -147,7 +150,16 @@ void free_slot_poly(Slot& s) {
 // stream, events and the small flag buffers of a slot (what kzg_quotient / kzg_evaluate need without an SRS)
 int ensure_slot_basics(kzg_ctx* ctx, Slot& s) {
     if (s.stream) return KZG_OK;
-    HIP_TRY(ctx, hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking));
+    {
+        // slot streams run the light kernels (sort, finalise, reduction, quotient): lowest priority, so that
+        // when an accumulation ends the NEXT accumulation (high-priority stream) takes the chip first and the
+        // ~180-VGPR reduction kernels fill in behind it instead of holding half of every SIMD's registers
+        int least = 0, greatest = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const char* v = std::getenv("KZG_STREAM_PRIORITIES");
+        const bool prio = !(v && v[0] == '0');
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio ? least : 0));
+    }
     for (auto& e : s.ev) HIP_TRY(ctx, hipEventCreate(&e));
     HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     HIP_TRY(ctx, hipMalloc(&s.d_small, 64 * 4));
@@ -191,7 +203,13 @@ void plan_reduce(kzg_ctx* ctx) {
 
 int setup_slots(kzg_ctx* ctx) {
     plan_reduce(ctx);
-    if (!ctx->heavy_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->heavy_stream, hipStreamNonBlocking));
+    if (!ctx->heavy_stream) {
+        int least = 0, greatest = 0;
+        HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        const char* v = std::getenv("KZG_STREAM_PRIORITIES");
+        const bool prio = !(v && v[0] == '0');
+        HIP_TRY(ctx, hipStreamCreateWithPriority(&ctx->heavy_stream, hipStreamNonBlocking, prio ? greatest : 0));
+    }
     const MsmConfig cfg = ctx->cfg;
     if (ctx->max_batch > sort_max_batch(cfg)) ctx->max_batch = sort_max_batch(cfg);
     const size_t B = ctx->max_batch;
@@ -209,13 +227,13 @@ int setup_slots(kzg_ctx* ctx) {
         free_slot_msm(s);
         HIP_TRY(ctx, hipMalloc(&s.d_cnt, (size_t)sort_count_entries((uint32_t)B, cfg) * 4 + 64));
         HIP_TRY(ctx, hipMalloc(&s.d_offs, ((size_t)cfg.nb * B + 1) * 4));
-        HIP_TRY(ctx, hipMalloc(&s.d_block_sums, 1024 * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_block_sums, (size_t)sort_workspace_words() * 4));  // scan block sums + tiled fine pass
         HIP_TRY(ctx, hipMalloc(&s.d_pairs, (pairs ? pairs : 1) * 8));
         HIP_TRY(ctx, hipMalloc(&s.d_sorted, (pairs ? pairs : 1) * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_buckets, (size_t)cfg.nb * B * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_part_a, (size_t)kMaxAccumLanes * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_part_b, (size_t)kMaxAccumLanes * kXyzzBytes));
-        HIP_TRY(ctx, hipMalloc(&s.d_heavy_list, (size_t)cfg.nb * B * 4));
+        HIP_TRY(ctx, hipMalloc(&s.d_heavy_ws, heavy_workspace_bytes()));
         HIP_TRY(ctx, hipMalloc(&s.d_arena, ctx->arena_records * B * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_final, ctx->final_records * B * kXyzzBytes));
         HIP_TRY(ctx, hipHostMalloc(&s.h_final, ctx->final_records * B * kXyzzBytes));
@@ -283,7 +301,7 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
     }
     const uint32_t lanes = accumulate_lanes((uint64_t)n * cfg.max_digits * batch);
     HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)nbt * kXyzzBytes, st));  // zero = infinity
-    HIP_TRY(ctx, hipMemsetAsync(s.d_small + 25, 0, 4, st));
+    HIP_TRY(ctx, hipMemsetAsync(s.d_heavy_ws, 0, 32, st));                        // long-bucket counters
     // hand over to the shared accumulation stream and back
     hipStream_t hs = ctx->serialize_accum ? ctx->heavy_stream : st;
     if (ctx->serialize_accum) {
@@ -298,8 +316,10 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         HIP_TRY(ctx, hipEventRecord(s.accum_ev, hs));
         HIP_TRY(ctx, hipStreamWaitEvent(st, s.accum_ev, 0));
     }
-    launch_bucket_finalize(st, s.d_offs, nbt, lanes, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_list, s.d_small + 25);
+    launch_bucket_finalize(st, s.d_offs, nbt, lanes, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_ws);
     HIP_TRY(ctx, hipMemcpyAsync(s.d_small + 26, s.d_offs + nbt, 4, hipMemcpyDeviceToDevice, st));  // references
+    // (gating the finalisation as well measured 3-5 % slower: it is short and wants to run at once)
+    if (ctx->gate_lds_bytes) hipLaunchKernelGGL(k_reduce_gate, dim3(1), dim3(64), ctx->gate_lds_bytes, st, (uint32_t*)nullptr);
     // reduction: Row / Col tree sums of every polynomial's bucket matrix, each split once more.
     // Vectors are polynomial-major ([p][index]); the final buffer holds four sections [p][len_k].
     {
@@ -369,6 +389,22 @@ bool host_tail_nonzero(const uint64_t* coeffs, size_t from, size_t n) {
 
 }  // namespace
 
+// Gate between a slot's bucket finalisation and its reduction trees: one workgroup that asks for more LDS than a CU
+// has left while TWO accumulation workgroups (41 KB each) live on it.  With the next slot's accumulation at full
+// occupancy the gate -- and, in stream order, the ~180-VGPR tree kernels behind it -- waits until that kernel's
+// first workgroups retire and its tail leaves half of every SIMD idle anyway.  Without it the trees start in the
+// accumulation's first phase, pin one of the two wave slots of many SIMDs for their whole latency-bound run and
+// cost the accumulation 0.85 ms (244 instead of 305 commitments/s).  Alone on the chip the
+// gate passes at once.
+__global__ void k_reduce_gate(uint32_t* sink) {
+    extern __shared__ uint32_t gate_lds[];
+    if (sink) {
+        gate_lds[threadIdx.x] = threadIdx.x;
+        __syncthreads();
+        sink[0] = gate_lds[63 - threadIdx.x];
+    }
+}
+
 // a tiny kernel for the device-pointer entry points: any non-zero Fr in [from, n)?
 __global__ void k_tail_nonzero(const uint32_t* __restrict__ c, uint64_t from, uint64_t n, uint32_t* __restrict__ flag) {
     uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -410,6 +446,15 @@ int kzg_ctx_create(int device, kzg_ctx** out) {
     ctx->device = device;
     if (const char* v = std::getenv("KZG_SERIALIZE_ACCUM")) ctx->serialize_accum = std::atoi(v) != 0;
     if (const char* v = std::getenv("KZG_ACCUM_LDS_KB")) ctx->accum_lds_bytes = (uint32_t)std::atoi(v) * 1024u;
+    if (const char* v = std::getenv("KZG_REDUCE_GATE_KB")) ctx->gate_lds_bytes = (uint32_t)std::atoi(v) * 1024u;
+    if (ctx->gate_lds_bytes > 64u * 1024u) {
+        // more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
+        if (hipFuncSetAttribute((const void*)k_reduce_gate, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)ctx->gate_lds_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            ctx->gate_lds_bytes = 64u * 1024u;
+        }
+    }
     *out = ctx;
     return KZG_OK;
 }

@@ -52,13 +52,14 @@ __host__ __device__ inline uint32_t accumulate_seg_len(uint32_t M, uint32_t lane
 // scalar recoding + two-level LDS counting sort of `batch` polynomials of n terms at once (polynomial p
 // at d_scalars + p * stride scalars; its buckets are [p * nb, (p+1) * nb)): fills
 // d_offs[0 .. batch*nb] (last = number of references) and d_sorted (bucket-major table references,
-// index | sign << 31).  d_cnt: sort_count_entries(max_batch, cfg) u32; d_block_sums: 1024 u32;
+// index | sign << 31).  d_cnt: sort_count_entries(max_batch, cfg) u32; d_ws: sort_workspace_words() u32;
 // d_pairs: batch * n * max_digits u64.  batch <= sort_max_batch(cfg).
 uint32_t sort_count_entries(uint32_t max_batch, MsmConfig cfg);
 uint32_t sort_max_batch(MsmConfig cfg);
+uint32_t sort_workspace_words();
 void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n, uint32_t batch,
                         uint64_t stride, uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt,
-                        uint32_t* d_block_sums, uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted);
+                        uint32_t* d_ws, uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted);
 // bucket accumulation (dominant kernel): one lane per segment of L sorted references
 constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on accumulate_lanes()
 // lanes (= segments) for at most max_refs references; a multiple of the workgroup size
@@ -66,10 +67,13 @@ uint32_t accumulate_lanes(uint64_t max_refs);
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
                               uint32_t nb, uint32_t lanes, void* d_buckets /* pre-zeroed */,
                               void* d_part_a, void* d_part_b, uint32_t lds_reserve_bytes);
-// adds the head / tail partials of buckets that span several segments (serial, or tree for long spans)
+// adds the head / tail partials of buckets that span several segments (serial for short runs, three passes of
+// 64-wide trees for long ones); d_heavy_ws: heavy_workspace_bytes() of scratch whose first 32 bytes (the
+// counters) the caller has zeroed -- ahead of time, so that nothing sits between the end of the accumulation
+// and this launch (a fill kernel there lets the next slot's accumulation take the chip first: +0.9 ms)
+size_t heavy_workspace_bytes();
 void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t lanes, const void* d_part_a,
-                            const void* d_part_b, void* d_buckets, uint32_t* d_heavy_list,
-                            uint32_t* d_heavy_count /* pre-zeroed */);
+                            const void* d_part_b, void* d_buckets, void* d_heavy_ws);
 // out[g] = sum_{q<len} in[g*gstride + q*estride], XYZZ records: log-depth tree per group;
 // up to four independent jobs per launch
 // group g reads in[(g / inner) * ostride + (g % inner) * gstride + q * estride], q < len

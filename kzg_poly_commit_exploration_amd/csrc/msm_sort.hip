@@ -168,8 +168,8 @@ KZG_DEV void for_each_digit(u32 k[8], MsmConfig cfg, F&& f) {
 //   scan    exclusive scan of that table: where each tile writes inside each coarse bin
 //   pass 2  same recoding; LDS cursors hand out positions; (fine key, table reference) pairs are
 //           written into their coarse bin
-//   pass 3  one workgroup per coarse bin: LDS histogram of the fine key -> bucket offsets, then the
-//           references are moved to their final, bucket-major position
+//   pass 3  the pairs of every coarse bin, in chunks: LDS histogram of the fine key -> scan -> bucket offsets,
+//           then the references are moved to their final, bucket-major position (below)
 // No global atomics, no rank array; order inside a bucket is arbitrary (the group law is commutative,
 // the result is bit-identical).
 constexpr int kSortBlock = 256;
@@ -273,41 +273,142 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_spread(const uint32_t* __re
     }
 }
 
-// one workgroup per coarse bin: [rs, re) of d_pairs -> bucket offsets + bucket-major references
-__global__ void __launch_bounds__(kSortBlock) k_sort_fine(const uint64_t* __restrict__ d_pairs,
-                                                          const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
-                                                          uint32_t fine_bits, uint32_t coarse_bins,
-                                                          const uint32_t* __restrict__ d_total,
-                                                          uint32_t* __restrict__ d_offs, uint32_t* __restrict__ d_sorted) {
+// ---- pass 3, tiled: every coarse bin [rs, re) of d_pairs is cut into chunks of `ch` pairs, one workgroup per
+// chunk, so that a bin holding most of the references (a 0/1 polynomial puts ALL of them into one bucket) is
+// sorted by as many workgroups as a uniform input uses.  Same count -> scan -> scatter shape as passes 1-2:
+//   plan     chunks per bin, exclusive scan -> prefix[bin] (one workgroup, <= 2048 bins)
+//   count    chunk (bin, j): LDS histogram of the fine key -> H[prefix[bin]*fine + key*nch(bin) + j]
+//   scan     exclusive scan of H: bins are consecutive, and inside a bin the order is key-major, chunk-minor,
+//            which is exactly the final order -> H becomes the global position of every (bucket, chunk) run
+//   offsets  d_offs[bucket] = H[.. key*nch + 0] (bin start for bins without pairs)
+//   scatter  chunk (bin, j): LDS cursors from H, references to their final position
+constexpr uint32_t kFineMaxChunks = 4096;            // H has kFineMaxChunks * 256 <= 2^20 entries (scan limit)
+constexpr uint32_t kWsBlockSums = 0;                 // workspace layout, u32 words
+constexpr uint32_t kWsPrefix = 1024;                 // kMaxCoarse + 1 entries
+constexpr uint32_t kWsDummy = kWsPrefix + kMaxCoarse + 8;
+constexpr uint32_t kWsTable = 4096;
+uint32_t sort_workspace_words() { return kWsTable + kFineMaxChunks * (uint32_t)kFineMax + 64; }
+
+// pairs per chunk: at most 2048 chunks come from the length, at most coarse_bins (<= 2048) from rounding up per bin
+static uint32_t fine_chunk_len(uint64_t max_pairs) {
+    static const uint64_t target = [] {
+        const char* v = std::getenv("KZG_FINE_CHUNKS");
+        uint64_t t = v ? std::strtoull(v, nullptr, 10) : 2048ull;
+        return t < 1 ? 1ull : (t > 2048 ? 2048ull : t);
+    }();
+    uint64_t ch = (max_pairs + target - 1) / target;
+    ch = (ch + 255) / 256 * 256;
+    return (uint32_t)(ch < 4096 ? 4096 : ch);
+}
+
+KZG_DEV uint32_t bin_start(const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles, uint32_t coarse_bins, uint32_t bin,
+                           uint32_t total) {
+    return bin < coarse_bins ? d_cnt_scanned[(size_t)bin * tiles] : total;
+}
+
+__global__ void __launch_bounds__(1024) k_fine_plan(const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
+                                                    uint32_t coarse_bins, const uint32_t* __restrict__ d_total,
+                                                    uint32_t ch, uint32_t* __restrict__ d_prefix) {
+    __shared__ u32 lds[1024];
+    const int t = threadIdx.x;
+    const uint32_t total = *d_total;
+    u32 v[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        uint32_t bin = 2 * t + q;
+        if (bin < coarse_bins) {
+            uint32_t rs = bin_start(d_cnt_scanned, tiles, coarse_bins, bin, total);
+            uint32_t re = bin_start(d_cnt_scanned, tiles, coarse_bins, bin + 1, total);
+            v[q] = (re - rs + ch - 1) / ch;
+        } else {
+            v[q] = 0;
+        }
+    }
+    u32 sum = v[0] + v[1];
+    lds[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        u32 add = t >= off ? lds[t - off] : 0u;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    u32 ex = lds[t] - sum;
+    if (2u * t < coarse_bins) d_prefix[2 * t] = ex;
+    if (2u * t + 1 < coarse_bins) d_prefix[2 * t + 1] = ex + v[0];
+    if (t == 1023) d_prefix[coarse_bins] = lds[1023];
+}
+
+// chunk k -> (bin, first pair, last pair, chunks of the bin, index inside the bin); false when k is past the end
+struct FineChunk {
+    uint32_t bin, beg, end, nch, j, base;
+};
+KZG_DEV bool locate_chunk(uint32_t k, const uint32_t* __restrict__ d_prefix, const uint32_t* __restrict__ d_cnt_scanned,
+                          uint32_t tiles, uint32_t coarse_bins, uint32_t total, uint32_t ch, FineChunk& c) {
+    if (k >= d_prefix[coarse_bins]) return false;
+    uint32_t lo = 0, hi = coarse_bins;  // smallest hi with prefix[hi] > k; prefix[lo] <= k
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (d_prefix[mid] <= k) lo = mid; else hi = mid;
+    }
+    c.bin = lo;
+    c.base = d_prefix[lo];
+    c.nch = d_prefix[lo + 1] - c.base;
+    c.j = k - c.base;
+    uint32_t rs = bin_start(d_cnt_scanned, tiles, coarse_bins, lo, total);
+    uint32_t re = bin_start(d_cnt_scanned, tiles, coarse_bins, lo + 1, total);
+    c.beg = rs + c.j * ch;
+    c.end = (re - c.beg < ch) ? re : c.beg + ch;
+    return true;
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_fine_count(const uint64_t* __restrict__ d_pairs,
+                                                           const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
+                                                           uint32_t fine_bits, uint32_t coarse_bins,
+                                                           const uint32_t* __restrict__ d_total, uint32_t ch,
+                                                           const uint32_t* __restrict__ d_prefix,
+                                                           uint32_t* __restrict__ d_table) {
     __shared__ u32 s_hist[kFineMax];
-    __shared__ u32 s_scan[kFineMax];
-    const uint32_t bin = blockIdx.x;
+    FineChunk c;
+    if (!locate_chunk(blockIdx.x, d_prefix, d_cnt_scanned, tiles, coarse_bins, *d_total, ch, c)) return;
     const uint32_t fine = 1u << fine_bits;
-    const uint32_t rs = d_cnt_scanned[(size_t)bin * tiles];
-    const uint32_t re = (bin + 1 < coarse_bins) ? d_cnt_scanned[(size_t)(bin + 1) * tiles] : *d_total;
     if (threadIdx.x < fine) s_hist[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t e = rs + threadIdx.x; e < re; e += kSortBlock) atomicAdd(&s_hist[(u32)(d_pairs[e] >> 32)], 1u);
+    for (uint32_t e = c.beg + threadIdx.x; e < c.end; e += kSortBlock) atomicAdd(&s_hist[(u32)(d_pairs[e] >> 32)], 1u);
     __syncthreads();
-    // exclusive scan of <= 256 counts (Hillis-Steele on the first `fine` lanes)
-    u32 v = threadIdx.x < fine ? s_hist[threadIdx.x] : 0u;
-    if (threadIdx.x < (u32)kFineMax) s_scan[threadIdx.x] = v;
+    if (threadIdx.x < fine) d_table[(size_t)c.base * fine + (size_t)threadIdx.x * c.nch + c.j] = s_hist[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) k_fine_offsets(const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
+                                                      uint32_t fine_bits, uint32_t coarse_bins, uint32_t nb_total,
+                                                      const uint32_t* __restrict__ d_total,
+                                                      const uint32_t* __restrict__ d_prefix,
+                                                      const uint32_t* __restrict__ d_table_scanned,
+                                                      uint32_t* __restrict__ d_offs) {
+    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nb_total) return;
+    const uint32_t bin = x >> fine_bits, key = x & ((1u << fine_bits) - 1u);
+    const uint32_t base = d_prefix[bin], nch = d_prefix[bin + 1] - base;
+    d_offs[x] = nch ? d_table_scanned[((size_t)base << fine_bits) + (size_t)key * nch]
+                    : bin_start(d_cnt_scanned, tiles, coarse_bins, bin, *d_total);
+}
+
+__global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const uint64_t* __restrict__ d_pairs,
+                                                             const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
+                                                             uint32_t fine_bits, uint32_t coarse_bins,
+                                                             const uint32_t* __restrict__ d_total, uint32_t ch,
+                                                             const uint32_t* __restrict__ d_prefix,
+                                                             const uint32_t* __restrict__ d_table_scanned,
+                                                             uint32_t* __restrict__ d_sorted) {
+    __shared__ u32 s_cur[kFineMax];
+    FineChunk c;
+    if (!locate_chunk(blockIdx.x, d_prefix, d_cnt_scanned, tiles, coarse_bins, *d_total, ch, c)) return;
+    const uint32_t fine = 1u << fine_bits;
+    if (threadIdx.x < fine) s_cur[threadIdx.x] = d_table_scanned[(size_t)c.base * fine + (size_t)threadIdx.x * c.nch + c.j];
     __syncthreads();
-    for (uint32_t off = 1; off < fine; off <<= 1) {
-        u32 add = (threadIdx.x < fine && threadIdx.x >= off) ? s_scan[threadIdx.x - off] : 0u;
-        __syncthreads();
-        if (threadIdx.x < fine) s_scan[threadIdx.x] += add;
-        __syncthreads();
-    }
-    if (threadIdx.x < fine) {
-        u32 ex = s_scan[threadIdx.x] - v;
-        d_offs[(bin << fine_bits) + threadIdx.x] = rs + ex;
-        s_hist[threadIdx.x] = rs + ex;  // becomes the cursor
-    }
-    __syncthreads();
-    for (uint32_t e = rs + threadIdx.x; e < re; e += kSortBlock) {
+    for (uint32_t e = c.beg + threadIdx.x; e < c.end; e += kSortBlock) {
         uint64_t pr = d_pairs[e];
-        u32 pos = atomicAdd(&s_hist[(u32)(pr >> 32)], 1u);
+        u32 pos = atomicAdd(&s_cur[(u32)(pr >> 32)], 1u);
         d_sorted[pos] = (u32)pr;
     }
 }
@@ -389,19 +490,34 @@ static void scan_inplace(hipStream_t s, uint32_t* d_buf, uint32_t count, uint32_
 }
 
 void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, uint32_t n, uint32_t batch,
-                        uint64_t stride, uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt, uint32_t* d_block_sums,
+                        uint64_t stride, uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt, uint32_t* d_ws,
                         uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted) {
     if (n == 0 || batch == 0) return;
     const uint32_t nb_total = cfg.nb * batch;
     SortGeom g = sort_geometry((uint64_t)n * batch, nb_total, cfg);
     BatchGeom bg{n, batch, stride, cfg.nb};
+    uint32_t* d_block_sums = d_ws + kWsBlockSums;
+    uint32_t* d_prefix = d_ws + kWsPrefix;
+    uint32_t* d_table = d_ws + kWsTable;
+    uint32_t* d_total = d_offs + nb_total;  // number of references, also the end of the offsets
     hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, cfg, g.tile,
                        g.tiles, g.fine_bits, g.coarse_bins, d_cnt);
-    scan_inplace(s, d_cnt, g.coarse_bins * g.tiles, d_block_sums, d_offs + nb_total);  // total refs -> offs[nb_total]
+    scan_inplace(s, d_cnt, g.coarse_bins * g.tiles, d_block_sums, d_total);
     hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg,
                        g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_pairs);
-    hipLaunchKernelGGL(k_sort_fine, dim3(g.coarse_bins), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
-                       g.coarse_bins, d_offs + nb_total, d_offs, d_sorted);
+    const uint64_t max_pairs = (uint64_t)n * batch * cfg.max_digits;
+    const uint32_t ch = fine_chunk_len(max_pairs);
+    const uint32_t max_chunks = (uint32_t)((max_pairs + ch - 1) / ch) + g.coarse_bins;  // <= kFineMaxChunks
+    const uint32_t fine = 1u << g.fine_bits;
+    hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(1024), 0, s, d_cnt, g.tiles, g.coarse_bins, d_total, ch, d_prefix);
+    hipLaunchKernelGGL(k_fine_count, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
+                       g.coarse_bins, d_total, ch, d_prefix, d_table);
+    // entries past the last chunk are stale; an exclusive scan never lets them reach the valid prefix
+    scan_inplace(s, d_table, max_chunks * fine, d_block_sums, d_ws + kWsDummy);
+    hipLaunchKernelGGL(k_fine_offsets, dim3((nb_total + 255) / 256), dim3(256), 0, s, d_cnt, g.tiles, g.fine_bits,
+                       g.coarse_bins, nb_total, d_total, d_prefix, d_table, d_offs);
+    hipLaunchKernelGGL(k_fine_scatter, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
+                       g.coarse_bins, d_total, ch, d_prefix, d_table, d_sorted);
 }
 
 }  // namespace kzg
