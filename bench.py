@@ -38,7 +38,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 DEGREE = 1 << 20
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_MAD_PEAK_T = 19.66        # v_mad_u64_u32 at a quarter of 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (T/s)
-MADS_PER_MADD = 10 * 288       # 8M + 2S field products x 2 x 12^2 multiply-adds
+MADS_PER_MADD = 8 * 288 + 2 * 233  # executed v_mad_u64_u32: 8 products x 2 x 12^2, 2 squarings x (89 + 12^2)
 
 
 def bench_coefficient_limbs(n):

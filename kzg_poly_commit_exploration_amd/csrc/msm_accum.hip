@@ -9,7 +9,7 @@
 // coefficients equal.  A lane closes a bucket it covers completely by storing it; the (at most two)
 // buckets it shares with its neighbours leave a head / tail partial that k_bucket_finalize adds up.
 //
-// Roofline: VALU (integer multiply) bound.  Per reference ~2900 v_mad_u64_u32 + ~6000 other VALU ops
+// Roofline: VALU (integer multiply) bound.  Per reference 2770 v_mad_u64_u32 + ~3800 other VALU ops
 // against 96 B gathered from the table + 4 B of reference.  Algorithmic HBM bytes per commitment are
 // those of SURVEY.md section 8(d): 128 B x n + 144 B.
 #include <cstdlib>
