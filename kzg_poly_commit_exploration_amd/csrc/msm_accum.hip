@@ -102,6 +102,10 @@ __global__ void __launch_bounds__(kAccumBlock) k_bucket_accumulate(const uint4* 
     // software pipeline: the gather of reference e+1 is issued before the ~2900 multiply-adds of e
     // (+1.5 % measured).  Two points in flight, with the reference itself loaded an iteration earlier, measured
     // 2 % SLOWER (232 instead of 206 VGPRs, same 2 waves/SIMD): the gather latency is already covered.
+    // Prefetching through LDS instead (global_load_lds, 188 VGPRs) measured the same as this, and forcing that
+    // build to 168 VGPRs = 3 waves/SIMD did not make the kernel faster alone (2.94-2.99 vs 2.97-2.99 ms) and
+    // starved the other slots' kernels (265 instead of 314 commitments/s): two waves per SIMD already saturate
+    // the quarter-rate multiplier (microbench: 14.8 T v_mad_u64_u32/s at 2 waves, 16.3 at 4; this kernel 14.5).
     u32 ref = sorted[start];
     Affine p = load_affine(table, ref & 0x7fffffffu);
     for (uint32_t e = start; e < end; e++) {
