@@ -10,7 +10,7 @@
 // Three launches over chunks of L coefficients per lane (coefficients past n count as zero):
 //   1. chunk Horner values, then a Kogge-Stone suffix scan inside the workgroup (multipliers
 //      z^(L 2^s), one Fr product per step), workgroup aggregates out;
-//   2. one workgroup scans the aggregates (multiplier z^(L*256));
+//   2. one workgroup scans the aggregates (multiplier z^(L*256); each lane takes a run of blocks);
 //   3. every lane replays its chunk from its now-known carry and writes q.
 // Algorithmic bytes: 32 B read + 32 B written per coefficient; the chunk
 // is read twice (the second time mostly from L2 / Infinity Cache).  HBM / latency bound.
@@ -107,53 +107,37 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_chunks(const uint32_t* __re
 
 // single workgroup: carries for every block.  d_block[b] in: aggregate of block b (zero carry-in);
 // out: d_block[b] = S at the first coefficient of block b+1 (its carry-in); d_result = P(z).
-__global__ void __launch_bounds__(1024) k_poly_blocks(uint32_t* __restrict__ d_block, uint32_t nblocks, FrArg zarg,
-                                                      uint32_t* __restrict__ d_result) {
-    __shared__ uint32_t lds[1024 * 8];
-    __shared__ uint32_t s_carry[8];
+// 256 lanes (one wave per SIMD, 86 VGPRs): small enough to start beside two resident accumulation waves of
+// another slot -- the former 1024-lane version needed 4 x 86 VGPRs per SIMD and waited ~1 ms for them.
+// Lane t owns `per` consecutive blocks: Horner over its blocks, Kogge-Stone across lanes, replay.
+__global__ void __launch_bounds__(kPolyBlock) k_poly_blocks(uint32_t* __restrict__ d_block, uint32_t nblocks, FrArg zarg,
+                                                            uint32_t* __restrict__ d_result) {
+    __shared__ uint32_t lds[kPolyBlock * 8];
     const Fr z = fr_from_arg(zarg);
-    const Fr zb = fr_pow_u32(z, kPolyTile);
-    const int t = threadIdx.x;
-    if (t < 8) s_carry[t] = 0;
+    const Fr zb = fr_pow_u32(z, kPolyTile);  // one block up
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (nblocks + kPolyBlock - 1) / kPolyBlock;
+    const uint32_t lo = t * per;
+    const uint32_t hi = lo + per < nblocks ? lo + per : nblocks;
+    Fr h = Fr::zero();
+    for (uint32_t u = hi; u-- > lo;) h = fe_add(fe_mul(h, zb), load_fr(d_block + (size_t)u * 8));
+    // H_t = sum_{v >= t} h_v * (zb^per)^(v - t)
+    Fr H = block_suffix_scan<kPolyBlock>(h, fr_pow_u32(zb, per), lds);
     __syncthreads();
-    // tiles of 1024 blocks, from the top of the polynomial down
-    uint32_t ntiles = (nblocks + 1023) / 1024;
-    for (uint32_t tile = ntiles; tile-- > 0;) {
-        uint32_t b = tile * 1024 + t;
-        Fr v = b < nblocks ? load_fr(d_block + (size_t)b * 8) : Fr::zero();
-        v = block_suffix_scan<1024>(v, zb, lds);
-        // add the carry from the tiles above: zb^(1024 - t) * carry (nothing to add for the top tile,
-        // which is the only tile up to 2^21 coefficients)
-        Fr carry;
 #pragma unroll
-        for (int i = 0; i < 8; i++) carry.l[i] = s_carry[i];
-        Fr full = v;
-        if (tile + 1 < ntiles) full = fe_add(v, fe_mul(fr_pow_u32(zb, 1024 - t), carry));
-        // full = S at the start of block b.  carry-in of block b is S at the start of block b+1.
+    for (int i = 0; i < 8; i++) lds[i * kPolyBlock + t] = H.l[i];
+    __syncthreads();
+    Fr s = Fr::zero();  // S at the first coefficient of the next lane's first block
+    if (t + 1 < (uint32_t)kPolyBlock) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) lds[i * 1024 + t] = full.l[i];
-        __syncthreads();
-        Fr next;
-        if (t + 1 < 1024) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) next.l[i] = lds[i * 1024 + t + 1];
-        } else {
-            next = carry;
-        }
-        if (b < nblocks) store_fr(d_block + (size_t)b * 8, next);
-        __syncthreads();
-        if (t == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) s_carry[i] = full.l[i];
-        }
-        __syncthreads();
+        for (int i = 0; i < 8; i++) s.l[i] = lds[i * kPolyBlock + t + 1];
     }
-    if (t == 0) {
-        Fr r;
-#pragma unroll
-        for (int i = 0; i < 8; i++) r.l[i] = s_carry[i];
-        store_fr(d_result, r);
+    for (uint32_t u = hi; u-- > lo;) {
+        Fr a = load_fr(d_block + (size_t)u * 8);
+        store_fr(d_block + (size_t)u * 8, s);  // carry-in of block u = S at the start of block u+1
+        s = fe_add(fe_mul(s, zb), a);
     }
+    if (t == 0) store_fr(d_result, s);  // S[0] = P(z)
 }
 
 __global__ void __launch_bounds__(kPolyBlock) k_poly_apply(const uint32_t* __restrict__ coeffs, uint32_t n, FrArg zarg,
@@ -208,7 +192,7 @@ void launch_quotient(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const 
     uint32_t nblocks = (n + kPolyTile - 1) / kPolyTile;
     hipLaunchKernelGGL(k_poly_chunks, dim3(nblocks), dim3(kPolyBlock), 0, s, d_coeffs, n, z, sc.d_chunk, sc.d_block,
                        sc.d_flags);
-    hipLaunchKernelGGL(k_poly_blocks, dim3(1), dim3(1024), 0, s, sc.d_block, nblocks, z, sc.d_result);
+    hipLaunchKernelGGL(k_poly_blocks, dim3(1), dim3(kPolyBlock), 0, s, sc.d_block, nblocks, z, sc.d_result);
     if (d_q && n > 1)
         hipLaunchKernelGGL(k_poly_apply, dim3(nblocks), dim3(kPolyBlock), 0, s, d_coeffs, n, z, sc.d_chunk, sc.d_block,
                            d_q);
