@@ -402,6 +402,24 @@ def test_naf_recoding_is_bit_exact(oracle, golden, monkeypatch):
         eng.close()
 
 
+def test_one_bucket_takes_everything_at_full_size(engines, oracle, golden):
+    """0/1-valued and constant polynomials (selector columns, bit vectors): every reference of a window falls
+    into one bucket.  Exercises the tiled fine sort and all three levels of the reduce-by-key trees
+    (csrc/msm_finalize.hip: 2^20 references -> 131072 segment partials -> 2048 chunks -> 32 groups -> 1)."""
+    secret = bytes.fromhex(golden["secret_be"])
+    rnd = random.Random(11)
+    for d in (1 << 16, 1 << 20):
+        n = d + 1
+        eng = engines.bench_srs(n)
+        cases = [[1] * n, [rnd.getrandbits(1) for _ in range(n)]]
+        if d == 1 << 16:  # the big size keeps to two cases (host-side conversion time)
+            cases.append([(3, 5, 1 << 60)[rnd.randrange(3)] for _ in range(n)])
+        for vals in cases:
+            c = oracle.fr_from_ints(vals)
+            want = oracle.p1_compress(oracle.commit_shortcut(c, secret))
+            assert eng.commit_limbs(c).compress() == want, (d, vals[:4])
+
+
 def test_zero_heavy_scalars_fill_the_accumulation_lanes(engines, oracle, golden):
     """The segment length follows the number of non-zero digits counted on the device: i128-style coefficients
     leave the upper windows empty, a sparse polynomial most of them; results and reference counts must agree."""
