@@ -37,7 +37,13 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 DEGREE = 1 << 20
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_MAD_PEAK_T = 19.66        # v_mad_u64_u32 at a quarter of 256 CU x 4 SIMD x 32 lanes x 2.4 GHz (T/s)
+# Measured issue costs on MI355X (tools/microbench mix, profiles/r01_microbench_mix.jsonl): a bare v_mad_u64_u32
+# loop reaches 33.4 T/s chip-wide (4 waves/SIMD; 30.6 T/s at the kernel's 2 waves/SIMD) and NOTHING hides behind it:
+# at 2 waves/SIMD a wave-level v_mad_u64_u32 costs ~5.13 issue cycles and a simple 32-bit VALU instruction ~2.98.
+VALU_MAD_PEAK_T = 33.4
+MAD_ISSUE_CYCLES, OTHER_ISSUE_CYCLES = 5.13, 2.98
+OTHER_VALU_PER_MADD = 3805     # SQ_INSTS_VALU per wave-level mixed addition (6575, profiles/r01_valu_pmc.json) - MADS_PER_MADD
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 MADS_PER_MADD = 8 * 288 + 2 * 233  # executed v_mad_u64_u32: 8 products x 2 x 12^2, 2 squarings x (89 + 12^2)
 
 
@@ -265,6 +271,8 @@ def main():
         refs = phase_ms.pop("references", [])
         madds = int(sum(refs) / max(1, len(refs)))   # one mixed addition per non-zero scalar digit (counted on the device)
         tmad = madds * MADS_PER_MADD / (avg_accum_ms * 1e-3) / 1e12 if avg_accum_ms > 0 else 0.0
+        issue_ms = (madds / 64.0) * (MADS_PER_MADD * MAD_ISSUE_CYCLES + OTHER_VALU_PER_MADD * OTHER_ISSUE_CYCLES) \
+            / (SIMDS * CLOCK_HZ) * 1e3
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
         if world == 1 and degree == DEGREE and os.path.exists(tpath):
@@ -306,7 +314,12 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "note": "integer-multiply (VALU) bound by construction: see valu"},
             "valu": {"achieved_Tmad_s": tmad, "peak_Tmad_s": VALU_MAD_PEAK_T, "frac": tmad / VALU_MAD_PEAK_T,
-                     "unit": "1e12 v_mad_u64_u32/s", "mixed_additions_per_launch": madds, **valu_pmc},
+                     "unit": "1e12 v_mad_u64_u32/s", "mixed_additions_per_launch": madds,
+                     # time the kernel's own VALU instruction mix needs if the SIMDs issued back to back
+                     "issue_model_ms": issue_ms, "issue_model_frac": issue_ms / avg_accum_ms if avg_accum_ms > 0 else 0.0,
+                     "note": "bound by total VALU issue, not by the multiply-adds alone: 2770 v_mad_u64_u32 + ~3800 "
+                             "other VALU instructions per mixed addition (the v_addc carry per multiply-add is 2770 of them)",
+                     **valu_pmc},
             "phase_ms": {k: sum(v) / len(v) for k, v in phase_ms.items()},
             "opening_proofs_per_sec": proofs_per_s,
             "quotient_ms": quotient_ms,

@@ -6,7 +6,8 @@
 // (reference src/scalar.rs:7-8), so buffers cross the C-ABI without conversion.
 //
 // CDNA4 has no carry-in on its 32x32->64 multiply-add (v_mad_u64_u32 D = S0*S1 + S2), and that
-// instruction issues at a quarter of the 32-bit add rate.  The multiplier is therefore written as
+// instruction costs about two simple 32-bit VALU instructions (measured, tools/microbench mix).
+// The multiplier is therefore written as
 // word-serial Montgomery (one row of a*b_i and one row of m*p per step), each row produced by a
 // chain of v_mad_u64_u32 whose high word feeds the next one (no separate carry instruction), and
 // folded into the accumulator by one v_addc_co_u32 chain: 2*n^2 multiply-adds + ~2*n^2 adds.

@@ -9,7 +9,7 @@
 // coefficients equal.  A lane closes a bucket it covers completely by storing it; the (at most two)
 // buckets it shares with its neighbours leave a head / tail partial that k_bucket_finalize adds up.
 //
-// Roofline: VALU (integer multiply) bound.  Per reference 2770 v_mad_u64_u32 + ~3800 other VALU ops
+// Roofline: VALU issue bound (a wave-level v_mad_u64_u32 costs ~5.1 issue cycles, a simple instruction ~3.0).  Per reference 2770 v_mad_u64_u32 + ~3800 other VALU ops
 // against 96 B gathered from the table + 4 B of reference.  Algorithmic HBM bytes per commitment are
 // those of SURVEY.md section 8(d): 128 B x n + 144 B.
 #include <cstdlib>
@@ -104,8 +104,8 @@ __global__ void __launch_bounds__(kAccumBlock) k_bucket_accumulate(const uint4* 
     // 2 % SLOWER (232 instead of 206 VGPRs, same 2 waves/SIMD): the gather latency is already covered.
     // Prefetching through LDS instead (global_load_lds, 188 VGPRs) measured the same as this, and forcing that
     // build to 168 VGPRs = 3 waves/SIMD did not make the kernel faster alone (2.94-2.99 vs 2.97-2.99 ms) and
-    // starved the other slots' kernels (265 instead of 314 commitments/s): two waves per SIMD already saturate
-    // the quarter-rate multiplier (microbench: 14.8 T v_mad_u64_u32/s at 2 waves, 16.3 at 4; this kernel 14.5).
+    // starved the other slots' kernels (265 instead of 314 commitments/s): the kernel is bound by VALU issue
+    // (VALUBusy 88 %), which two waves per SIMD already keep busy.
     u32 ref = sorted[start];
     Affine p = load_affine(table, ref & 0x7fffffffu);
     for (uint32_t e = start; e < end; e++) {

@@ -42,6 +42,35 @@ __global__ void __launch_bounds__(256) k_mad(u64* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// how many full-rate VALU instructions hide behind one quarter-rate v_mad_u64_u32?  R independent v_add_u32
+// per multiply-add, 8 independent multiply-add chains.
+template <int R>
+__global__ void __launch_bounds__(256) k_mad_mix(u64* out, int iters) {
+    u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 77u;
+    u64 acc[CHAINS];
+    u32 x[CHAINS];
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) {
+        acc[k] = a + k;
+        x[k] = b + k;
+    }
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+#pragma unroll
+            for (int k = 0; k < CHAINS; k++) {
+                asm volatile("v_mad_u64_u32 %0, s[72:73], %1, %2, %0" : "+v"(acc[k]) : "v"(a), "v"(b) : "s72", "s73");
+#pragma unroll
+                for (int j = 0; j < R; j++) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x[(k + j + 1) & 7]) : "v"(a));
+            }
+        }
+    }
+    u64 s = 0;
+#pragma unroll
+    for (int k = 0; k < CHAINS; k++) s ^= acc[k] + x[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void __launch_bounds__(256) k_mullo(u64* out, int iters) {
     u32 a = threadIdx.x * 2654435761u + 12345u;
     u32 acc[CHAINS];
@@ -354,7 +383,33 @@ static int run_gather_footprints() {
     return 0;
 }
 
+template <int R>
+static void run_mix(u64* out, int cus, int wps) {
+    const int iters = 2000, grid = cus * wps;
+    double ms = time_kernel(k_mad_mix<R>, grid, 256, 5, out, iters);
+    double n_mad = (double)grid * 256 * iters * 8 * CHAINS;
+    printf("{\"bench\": \"mad_plus_adds\", \"adds_per_mad\": %d, \"waves_per_simd\": %d, \"ms\": %.4f, \"Tmad_s\": %.2f}\n", R, wps, ms,
+           n_mad / ms / 1e9);
+}
+static int run_mix_all() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    int cus = prop.multiProcessorCount;
+    u64* out;
+    CHECK(hipMalloc(&out, sizeof(u64) * 256 * 8 * 1024));
+    for (int wps : {1, 2, 3, 4}) {
+        run_mix<0>(out, cus, wps);
+        run_mix<1>(out, cus, wps);
+        run_mix<2>(out, cus, wps);
+        run_mix<3>(out, cus, wps);
+        run_mix<4>(out, cus, wps);
+        run_mix<6>(out, cus, wps);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "mix")) return run_mix_all();
     if (argc > 1 && !strcmp(argv[1], "gather")) return run_gather_calibration();
     if (argc > 1 && !strcmp(argv[1], "footprint")) return run_gather_footprints();
     hipDeviceProp_t prop;
