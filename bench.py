@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 # at 2 waves/SIMD a wave-level v_mad_u64_u32 costs ~5.13 issue cycles and a simple 32-bit VALU instruction ~2.98.
 VALU_MAD_PEAK_T = 33.4
 MAD_ISSUE_CYCLES, OTHER_ISSUE_CYCLES = 5.13, 2.98
-OTHER_VALU_PER_MADD = 3575     # SQ_INSTS_VALU per wave-level mixed addition (profiles/r01_valu_pmc.json) - MADS_PER_MADD, less the 230 column clears removed since
+OTHER_VALU_PER_MADD = 3578     # SQ_INSTS_VALU per wave-level mixed addition (6348, profiles/r01_valu_pmc.json) - MADS_PER_MADD
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 MADS_PER_MADD = 8 * 288 + 2 * 233  # executed v_mad_u64_u32: 8 products x 2 x 12^2, 2 squarings x (89 + 12^2)
 
@@ -317,7 +317,7 @@ def main():
                      "unit": "1e12 v_mad_u64_u32/s", "mixed_additions_per_launch": madds,
                      # time the kernel's own VALU instruction mix needs if the SIMDs issued back to back
                      "issue_model_ms": issue_ms, "issue_model_frac": issue_ms / avg_accum_ms if avg_accum_ms > 0 else 0.0,
-                     "note": "bound by total VALU issue, not by the multiply-adds alone: 2770 v_mad_u64_u32 + ~3800 "
+                     "note": "bound by total VALU issue, not by the multiply-adds alone: 2770 v_mad_u64_u32 + ~3580 "
                              "other VALU instructions per mixed addition (the v_addc carry per multiply-add is 2770 of them)",
                      **valu_pmc},
             "phase_ms": {k: sum(v) / len(v) for k, v in phase_ms.items()},
