@@ -117,6 +117,12 @@ struct Evaluation {  // src/polynomial.rs:249-253
                        result.l.data(), out.p1.data()), setup.ctx());
         return out;
     }
+    // :276-294; s_g2 = setup_artifacts[1].g2 as blst_p2 (36 x u64).  Host-side pairing check.
+    bool verify_proof(const G1Point& proof, const G1Point& commitment, const uint64_t s_g2[36]) const {
+        int valid = 0;
+        check(kzg_verify_proof(commitment.p1.data(), proof.p1.data(), point.l.data(), result.l.data(), s_g2, &valid), nullptr);
+        return valid == 1;
+    }
 };
 
 }  // namespace kzg_api

@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "kzg_set_max_batch", "kzg_max_batch", "kzg_commit_batch_submit", "kzg_wait_batch",
     "kzg_open_batch_submit", "kzg_wait_open_batch", "kzg_g1_uncompress",
     "kzg_dev_alloc", "kzg_dev_free", "kzg_dev_upload", "kzg_dev_download",
-    "kzg_g1_sum", "kzg_g1_compress", "kzg_set_timing", "kzg_get_times", "kzg_msm_config",
+    "kzg_g1_sum", "kzg_g1_compress", "kzg_verify_proof", "kzg_set_timing", "kzg_get_times", "kzg_msm_config",
 ]
 
 
@@ -115,6 +115,7 @@ def load_library():
         "kzg_g1_compress": (i, [vp, vp]),
         "kzg_set_timing": (i, [vp, i]),
         "kzg_get_times": (i, [vp, i, C.POINTER(KernelTimes)]),
+        "kzg_verify_proof": (i, [vp, vp, vp, vp, vp, C.POINTER(i)]),
         "kzg_msm_config": (i, [vp, C.POINTER(i), C.POINTER(i), C.POINTER(sz), C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
@@ -467,6 +468,16 @@ class SetupArtifactsGenerator:
         return eng
 
 
+def verify_proof(commitment, proof, z, y, s_g2):
+    """kzg_verify_proof: e(proof, [s]G2 - [z]G2) == e(commitment - [y]G1, G2) on the host."""
+    lib = load_library()
+    g2 = np.ascontiguousarray(s_g2, dtype=np.uint64).reshape(36)
+    ok = C.c_int(0)
+    zl, yl = z.limbs(), y.limbs()
+    _check(lib.kzg_verify_proof(_ptr(commitment.p1), _ptr(proof.p1), _ptr(zl), _ptr(yl), _ptr(g2), C.byref(ok)))
+    return bool(ok.value)
+
+
 # ---------------------------------------------------------------------------------------------
 # Polynomial / Evaluation: reference src/polynomial.rs
 # ---------------------------------------------------------------------------------------------
@@ -521,3 +532,7 @@ class Evaluation:
 
     def generate_proof(self, polynomial, setup):  # src/polynomial.rs:260-269
         return setup.open_limbs(polynomial.limbs, self.point, self.result)
+
+    def verify_proof(self, proof, commitment, s_g2):  # src/polynomial.rs:276-294
+        """s_g2: setup_artifacts[1].g2 as 36 x u64 (blst_p2).  Host-side pairing check of the library."""
+        return verify_proof(commitment, proof, self.point, self.result, s_g2)

@@ -21,6 +21,7 @@
 #include "../../include/kzg_mi355x.h"
 #include "engine.h"
 #include "host_field.hpp"
+#include "host_pairing.hpp"
 
 using namespace kzg;
 namespace hf = kzg_host;
@@ -1057,6 +1058,15 @@ int kzg_g1_uncompress(const uint8_t in[48], uint64_t out_p1[18]) {
     hf::P1 p;
     if (!hf::p1_uncompress(p, in)) return KZG_ERR_INVALID_ARG;
     write_p1(out_p1, p);
+    return KZG_OK;
+}
+
+int kzg_verify_proof(const uint64_t commitment_p1[18], const uint64_t proof_p1[18], const uint64_t z[4],
+                     const uint64_t y[4], const uint64_t s_g2_p2[36], int* valid) {
+    if (!commitment_p1 || !proof_p1 || !z || !y || !s_g2_p2 || !valid) return KZG_ERR_INVALID_ARG;
+    int r = hf::verify_proof(commitment_p1, proof_p1, z, y, s_g2_p2);
+    if (r < 0) return KZG_ERR_INVALID_ARG;
+    *valid = r;
     return KZG_OK;
 }
 

@@ -141,6 +141,14 @@ def test_gpu_proofs_pass_the_references_pairing_check(oracle, twin):
             pi = twin.g1_uncompress(proof.compress())
             assert PT.verify_proof(C, pi, z.v, evaluation.result.v, secret), degree
             assert not PT.verify_proof(C, pi, z.v, (evaluation.result.v + 1) % K.R_MODULUS, secret)
+            # and the library's own verify_proof (src/polynomial.rs:276-294) closes the loop of src/lib.rs:16-33
+            s = int.from_bytes(secret, "big") % K.R_MODULUS
+            (xa, xb), (ya, yb) = PT.g2_mul(PT.G2, s)
+            mont = lambda v: [((v << 384) % twin.P >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]  # noqa: E731
+            s_g2 = mont(xa) + mont(xb) + mont(ya) + mont(yb) + mont(1) + mont(0)
+            assert evaluation.verify_proof(proof, commitment, s_g2) is True
+            wrong = K.Evaluation(z, K.Scalar((evaluation.result.v + 1) % K.R_MODULUS))
+            assert wrong.verify_proof(proof, commitment, s_g2) is False
         finally:
             setup.close()
 
