@@ -428,6 +428,61 @@ def test_one_bucket_takes_everything_at_full_size(engines, oracle, golden):
             assert eng.commit_limbs(c).compress() == want, (d, vals[:4])
 
 
+def test_concurrent_host_threads_share_one_context(engines, oracle, golden):
+    """The reference's callers include `cargo test` threads (re-entrant per context).  Four host
+    threads hammer one engine through the synchronous entry points (ctypes drops the GIL inside the calls) while
+    a second engine on the same device works beside them; every result must still be exact."""
+    import threading
+
+    secret = bytes.fromhex(golden["secret_be"])
+    eng = engines.bench_srs(SMALL_N)
+    srs = oracle.srs_g1(SMALL_N, secret)
+    other = K.SetupArtifactsGenerator(secret).take(1001)
+    rnd = random.Random(5)
+    jobs = []
+    for t in range(4):
+        n = rnd.randrange(2, SMALL_N + 1)
+        c = K.scalars_to_limbs([rnd.randrange(K.R_MODULUS) for _ in range(n)])
+        z = oracle.fr_from_int(rnd.randrange(K.R_MODULUS))
+        yv = oracle.poly_evaluate(c, z)
+        rc, want_c = oracle.commit_naive(c, srs) if n <= 300 else oracle.commit_pippenger(c, srs, threads=2)
+        assert rc == 0
+        rc, want_p = oracle.generate_proof(c, z, yv, srs)
+        assert rc == 0
+        jobs.append((c, K.Scalar.from_limbs(z), K.Scalar.from_limbs(yv), oracle.p1_compress(want_c), oracle.p1_compress(want_p)))
+    errors = []
+
+    def worker(job):
+        c, z, y, want_c, want_p = job
+        try:
+            for _ in range(6):
+                if eng.commit_limbs(c).compress() != want_c:
+                    errors.append("commit")
+                if eng.open_limbs(c, z, y).compress() != want_p:
+                    errors.append("open")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    def side():
+        try:
+            c1 = oracle.bench_coefficients(1001)
+            for _ in range(6):
+                if other.commit_limbs(c1).compress().hex() != _case(golden, 1000)["commit"]:
+                    errors.append("side commit")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(j,)) for j in jobs] + [threading.Thread(target=side)]
+    try:
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors[:3]
+    finally:
+        other.close()
+
+
 def test_zero_heavy_scalars_fill_the_accumulation_lanes(engines, oracle, golden):
     """The segment length follows the number of non-zero digits counted on the device: i128-style coefficients
     leave the upper windows empty, a sparse polynomial most of them; results and reference counts must agree."""
