@@ -171,6 +171,10 @@ int kzg_g1_uncompress(const uint8_t in[48], uint64_t out_p1[18]);
  * when s_g2 is not on the curve.  Next-row component. */
 int kzg_verify_proof(const uint64_t commitment_p1[18], const uint64_t proof_p1[18], const uint64_t z[4],
                      const uint64_t y[4], const uint64_t s_g2_p2[36], int* valid);
+/* n independent checks against the same setup (BASELINE config 5: a batch of openings and their verification),
+ * spread over the host's cores; element i of every array belongs to check i (18 / 18 / 4 / 4 u64, one int). */
+int kzg_verify_proof_batch(const uint64_t* commitments_p1, const uint64_t* proofs_p1, const uint64_t* zs,
+                           const uint64_t* ys, const uint64_t s_g2_p2[36], size_t n, int* valid);
 
 /* ---- measurement -------------------------------------------------------------------------- */
 

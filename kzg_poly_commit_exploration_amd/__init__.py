@@ -44,7 +44,7 @@ ABI_SYMBOLS = [
     "kzg_set_max_batch", "kzg_max_batch", "kzg_commit_batch_submit", "kzg_wait_batch",
     "kzg_open_batch_submit", "kzg_wait_open_batch", "kzg_g1_uncompress",
     "kzg_dev_alloc", "kzg_dev_free", "kzg_dev_upload", "kzg_dev_download",
-    "kzg_g1_sum", "kzg_g1_compress", "kzg_verify_proof", "kzg_set_timing", "kzg_get_times", "kzg_msm_config",
+    "kzg_g1_sum", "kzg_g1_compress", "kzg_verify_proof", "kzg_verify_proof_batch", "kzg_set_timing", "kzg_get_times", "kzg_msm_config",
 ]
 
 
@@ -116,6 +116,7 @@ def load_library():
         "kzg_set_timing": (i, [vp, i]),
         "kzg_get_times": (i, [vp, i, C.POINTER(KernelTimes)]),
         "kzg_verify_proof": (i, [vp, vp, vp, vp, vp, C.POINTER(i)]),
+        "kzg_verify_proof_batch": (i, [vp, vp, vp, vp, vp, sz, vp]),
         "kzg_msm_config": (i, [vp, C.POINTER(i), C.POINTER(i), C.POINTER(sz), C.POINTER(i)]),
     }
     for name, (res, args) in sig.items():
@@ -476,6 +477,21 @@ def verify_proof(commitment, proof, z, y, s_g2):
     zl, yl = z.limbs(), y.limbs()
     _check(lib.kzg_verify_proof(_ptr(commitment.p1), _ptr(proof.p1), _ptr(zl), _ptr(yl), _ptr(g2), C.byref(ok)))
     return bool(ok.value)
+
+
+def verify_proof_batch(commitments, proofs, zs, ys, s_g2):
+    """kzg_verify_proof_batch: one verdict per (commitment, proof, z, y), checks spread over the host cores."""
+    lib = load_library()
+    n = len(commitments)
+    assert len(proofs) == n and len(zs) == n and len(ys) == n
+    g2 = np.ascontiguousarray(s_g2, dtype=np.uint64).reshape(36)
+    cs = np.ascontiguousarray(np.stack([c.p1 for c in commitments]) if n else np.zeros((0, 18)), dtype=np.uint64)
+    ps = np.ascontiguousarray(np.stack([p.p1 for p in proofs]) if n else np.zeros((0, 18)), dtype=np.uint64)
+    zl = np.ascontiguousarray(np.stack([z.limbs() for z in zs]) if n else np.zeros((0, 4)), dtype=np.uint64)
+    yl = np.ascontiguousarray(np.stack([y.limbs() for y in ys]) if n else np.zeros((0, 4)), dtype=np.uint64)
+    ok = np.zeros(max(n, 1), dtype=np.int32)
+    _check(lib.kzg_verify_proof_batch(_ptr(cs), _ptr(ps), _ptr(zl), _ptr(yl), _ptr(g2), n, _ptr(ok)))
+    return [bool(v) for v in ok[:n]]
 
 
 # ---------------------------------------------------------------------------------------------

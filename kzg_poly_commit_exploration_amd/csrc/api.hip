@@ -1070,6 +1070,33 @@ int kzg_verify_proof(const uint64_t commitment_p1[18], const uint64_t proof_p1[1
     return KZG_OK;
 }
 
+int kzg_verify_proof_batch(const uint64_t* commitments_p1, const uint64_t* proofs_p1, const uint64_t* zs,
+                           const uint64_t* ys, const uint64_t s_g2_p2[36], size_t n, int* valid) {
+    if ((!commitments_p1 || !proofs_p1 || !zs || !ys || !valid) && n) return KZG_ERR_INVALID_ARG;
+    if (!s_g2_p2) return KZG_ERR_INVALID_ARG;
+    size_t nthreads = std::thread::hardware_concurrency();
+    if (nthreads == 0) nthreads = 1;
+    if (nthreads > n) nthreads = n;
+    std::vector<int> results(n, 0);
+    auto work = [&](size_t t) {
+        for (size_t i = t; i < n; i += nthreads)
+            results[i] = hf::verify_proof(commitments_p1 + 18 * i, proofs_p1 + 18 * i, zs + 4 * i, ys + 4 * i, s_g2_p2);
+    };
+    if (nthreads <= 1) {
+        if (n) work(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nthreads; t++) pool.emplace_back(work, t);
+        work(0);
+        for (auto& th : pool) th.join();
+    }
+    for (size_t i = 0; i < n; i++) {
+        if (results[i] < 0) return KZG_ERR_INVALID_ARG;
+        valid[i] = results[i];
+    }
+    return KZG_OK;
+}
+
 // ---- measurement ---------------------------------------------------------------------------------
 
 int kzg_set_timing(kzg_ctx* ctx, int enabled) {

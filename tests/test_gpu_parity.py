@@ -695,6 +695,37 @@ def test_batched_openings_equal_individual(oracle, golden):
         eng.close()
 
 
+def test_batch_of_openings_and_their_verification(twin, golden):
+    """BASELINE config 5 in miniature: a batch of openings on the GPU (kzg_open_batch_submit) and the pairing
+    verification of every one of them on the host (kzg_verify_proof_batch), as src/lib.rs:16-33 does one by one."""
+    import pairing_twin as PT
+
+    rnd = random.Random(64)
+    secret = bytes(rnd.randrange(256) for _ in range(32))
+    s = int.from_bytes(secret, "big") % K.R_MODULUS
+    n = 1025
+    eng = K.SetupArtifactsGenerator(secret).take(n)
+    try:
+        b = eng.set_max_batch(8)
+        polys = [K.scalars_to_limbs([K.Scalar.from_i128(rnd.randrange(-(1 << 127), 1 << 127)).v for _ in range(n)])
+                 for _ in range(b)]
+        zs = [K.Scalar.from_i128(rnd.randrange(-(1 << 127), 1 << 127)) for _ in polys]
+        ys = [eng.evaluate_limbs(p, z) for p, z in zip(polys, zs)]
+        commitments = eng.commit_batch_limbs(polys)
+        proofs = eng.open_batch_limbs(polys, zs, ys)
+        assert not any(isinstance(p, K.KzgError) for p in proofs)
+        (xa, xb), (ya, yb) = PT.g2_mul(PT.G2, s)
+        mont = lambda v: [((v << 384) % twin.P >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]  # noqa: E731
+        s_g2 = mont(xa) + mont(xb) + mont(ya) + mont(yb) + mont(1) + mont(0)
+        assert K.verify_proof_batch(commitments, proofs, zs, ys, s_g2) == [True] * b
+        ys_bad = list(ys)
+        ys_bad[b // 2] = K.Scalar((ys[b // 2].v + 1) % K.R_MODULUS)
+        verdicts = K.verify_proof_batch(commitments, proofs, zs, ys_bad, s_g2)
+        assert verdicts == [i != b // 2 for i in range(b)]
+    finally:
+        eng.close()
+
+
 # ---------------------------------------------------------------- 2^22 (BASELINE config 4 size, one GPU)
 
 def test_degree_2_22_commit_and_proof_golden(oracle, golden):

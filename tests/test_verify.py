@@ -68,6 +68,30 @@ def test_verify_proof_accepts_and_rejects_like_the_pairing_twin(twin, oracle):
     assert K.Evaluation(K.Scalar(99), K.Scalar(8)).verify_proof(inf, _p1(twin, oracle, commitment), s_g2) is False
 
 
+def test_verify_proof_batch_matches_single_checks(twin, oracle):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pairing_twin as PT
+
+    rnd = random.Random(77)
+    P, R = twin.P, twin.R
+    s = rnd.randrange(1, R)
+    secret_be = s.to_bytes(32, "big")
+    s_g2 = _p2_limbs(PT.g2_mul(PT.G2, s), P)
+    cs, ps, zs, ys, want = [], [], [], [], []
+    for i in range(6):
+        coeffs = [rnd.randrange(R) for _ in range(rnd.randrange(2, 6))]
+        z = rnd.randrange(R)
+        y = sum(c * pow(z, k, R) for k, c in enumerate(coeffs)) % R
+        good = i % 3 != 1
+        cs.append(_p1(twin, oracle, twin.commit_shortcut(coeffs, secret_be)))
+        ps.append(_p1(twin, oracle, twin.proof_shortcut(coeffs, z, y, secret_be)))
+        zs.append(K.Scalar(z))
+        ys.append(K.Scalar(y if good else (y + 5) % R))
+        want.append(good)
+    assert K.verify_proof_batch(cs, ps, zs, ys, s_g2) == want
+    assert K.verify_proof_batch([], [], [], [], s_g2) == []
+
+
 def test_verify_proof_rejects_a_g2_point_off_the_curve(twin):
     P = twin.P
     bad = _p2_limbs(((1, 2), (3, 4)), P)
