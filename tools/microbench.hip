@@ -71,6 +71,54 @@ __global__ void __launch_bounds__(256) k_mad_mix(u64* out, int iters) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// carry handling of six multiply-adds: (A) one v_addc per carry mask, as the multiplier does today; (B) the six masks
+// compressed by a carry-save adder tree on the SCALAR unit (17 s_*_b64) into masks of weight 1, 2, 4 -> three v_addc.
+template <int MODE>
+__global__ void __launch_bounds__(256) k_mad_carry(u64* out, int iters) {
+    u32 a = threadIdx.x * 2654435761u + 12345u, b = blockIdx.x * 40503u + 77u;
+    u64 acc = a;
+    u32 o1 = 0, o2 = 0, o4 = 0;
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            if (MODE == 0) {
+                asm volatile(
+                    "v_mad_u64_u32 %0, s[72:73], %2, %3, %0\n\tv_mad_u64_u32 %0, s[74:75], %2, %3, %0\n\t"
+                    "v_mad_u64_u32 %0, s[76:77], %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, s[72:73]\n\t"
+                    "v_mad_u64_u32 %0, s[72:73], %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, s[74:75]\n\t"
+                    "v_mad_u64_u32 %0, s[74:75], %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, s[76:77]\n\t"
+                    "v_mad_u64_u32 %0, s[76:77], %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, s[72:73]\n\t"
+                    "v_addc_co_u32 %1, vcc, 0, %1, s[74:75]\n\tv_addc_co_u32 %1, vcc, 0, %1, s[76:77]"
+                    : "+v"(acc), "+v"(o1)
+                    : "v"(a), "v"(b)
+                    : "vcc", "s72", "s73", "s74", "s75", "s76", "s77");
+            } else {
+                asm volatile(
+                    "v_mad_u64_u32 %0, s[72:73], %4, %5, %0\n\tv_mad_u64_u32 %0, s[74:75], %4, %5, %0\n\t"
+                    "v_mad_u64_u32 %0, s[76:77], %4, %5, %0\n\tv_mad_u64_u32 %0, s[78:79], %4, %5, %0\n\t"
+                    "v_mad_u64_u32 %0, s[80:81], %4, %5, %0\n\tv_mad_u64_u32 %0, s[82:83], %4, %5, %0\n\t"
+                    "s_xor_b64 s[84:85], s[72:73], s[74:75]\n\ts_and_b64 s[86:87], s[72:73], s[74:75]\n\t"
+                    "s_and_b64 s[88:89], s[76:77], s[84:85]\n\ts_xor_b64 s[84:85], s[84:85], s[76:77]\n\t"
+                    "s_or_b64 s[86:87], s[86:87], s[88:89]\n\t"                       // s1 = 84, c1 = 86
+                    "s_xor_b64 s[88:89], s[78:79], s[80:81]\n\ts_and_b64 s[90:91], s[78:79], s[80:81]\n\t"
+                    "s_and_b64 s[72:73], s[82:83], s[88:89]\n\ts_xor_b64 s[88:89], s[88:89], s[82:83]\n\t"
+                    "s_or_b64 s[90:91], s[90:91], s[72:73]\n\t"                       // s2 = 88, c2 = 90
+                    "s_and_b64 s[72:73], s[84:85], s[88:89]\n\ts_xor_b64 s[84:85], s[84:85], s[88:89]\n\t"  // c3 = 72, s = 84
+                    "s_xor_b64 s[74:75], s[86:87], s[90:91]\n\ts_and_b64 s[76:77], s[86:87], s[90:91]\n\t"
+                    "s_and_b64 s[78:79], s[72:73], s[74:75]\n\ts_xor_b64 s[74:75], s[74:75], s[72:73]\n\t"  // t = 74
+                    "s_or_b64 s[76:77], s[76:77], s[78:79]\n\t"                        // u = 76
+                    "v_addc_co_u32 %1, vcc, 0, %1, s[84:85]\n\tv_addc_co_u32 %2, vcc, 0, %2, s[74:75]\n\t"
+                    "v_addc_co_u32 %3, vcc, 0, %3, s[76:77]"
+                    : "+v"(acc), "+v"(o1), "+v"(o2), "+v"(o4)
+                    : "v"(a), "v"(b)
+                    : "vcc", "scc", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84",
+                      "s85", "s86", "s87", "s88", "s89", "s90", "s91");
+            }
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc + o1 + 2 * o2 + 4 * o4;
+}
+
 __global__ void __launch_bounds__(256) k_mullo(u64* out, int iters) {
     u32 a = threadIdx.x * 2654435761u + 12345u;
     u32 acc[CHAINS];
@@ -329,6 +377,7 @@ static double time_kernel(K kern, int grid, int block, int reps, A... args) {
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, args...);
+    CHECK(hipGetLastError());
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
     for (int r = 0; r < reps; r++) hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, 0, args...);
@@ -408,7 +457,47 @@ static int run_mix_all() {
     return 0;
 }
 
+static int run_carry_debug() {
+    u64* out;
+    CHECK(hipMalloc(&out, sizeof(u64) * 256 * 8));
+    CHECK(hipMemset(out, 0xff, sizeof(u64) * 256 * 8));
+    for (int mode = 0; mode < 2; mode++) {
+        if (mode == 0) hipLaunchKernelGGL(k_mad_carry<0>, dim3(2), dim3(256), 0, 0, out, 3);
+        else hipLaunchKernelGGL(k_mad_carry<1>, dim3(2), dim3(256), 0, 0, out, 3);
+        hipError_t e1 = hipGetLastError();
+        hipError_t e2 = hipDeviceSynchronize();
+        u64 h[4];
+        CHECK(hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost));
+        printf("mode %d launch=%s sync=%s out0=%016llx out1=%016llx\n", mode, hipGetErrorString(e1), hipGetErrorString(e2),
+               (unsigned long long)h[0], (unsigned long long)h[1]);
+    }
+    return 0;
+}
+
+static int run_carry() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    int cus = prop.multiProcessorCount;
+    u64* out;
+    CHECK(hipMalloc(&out, sizeof(u64) * 256 * 8 * 1024));
+    std::vector<u64> h0(256), h1(256);
+    for (int wps : {1, 2, 3, 4}) {
+        const int iters = 2000, grid = cus * wps;
+        double n_mad = (double)grid * 256 * iters * 8 * 6;
+        double ms0 = time_kernel(k_mad_carry<0>, grid, 256, 5, out, iters);
+        CHECK(hipMemcpy(h0.data(), out, 256 * 8, hipMemcpyDeviceToHost));
+        double ms1 = time_kernel(k_mad_carry<1>, grid, 256, 5, out, iters);
+        CHECK(hipMemcpy(h1.data(), out, 256 * 8, hipMemcpyDeviceToHost));
+        bool same = h0 == h1;
+        printf("{\"bench\": \"carry_handling\", \"waves_per_simd\": %d, \"addc_per_mad_ms\": %.4f, \"salu_tree_ms\": %.4f, \"Tmad_s_addc\": %.2f, \"Tmad_s_tree\": %.2f, \"same_result\": %s}\n",
+               wps, ms0, ms1, n_mad / ms0 / 1e9, n_mad / ms1 / 1e9, same ? "true" : "false");
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "carrydbg")) return run_carry_debug();
+    if (argc > 1 && !strcmp(argv[1], "carry")) return run_carry();
     if (argc > 1 && !strcmp(argv[1], "mix")) return run_mix_all();
     if (argc > 1 && !strcmp(argv[1], "gather")) return run_gather_calibration();
     if (argc > 1 && !strcmp(argv[1], "footprint")) return run_gather_footprints();
