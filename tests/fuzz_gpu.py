@@ -1,5 +1,5 @@
 """Randomised differential fuzz of the C-ABI against the oracle (GPU; not collected by pytest).
-    python tests/fuzz_gpu.py [seconds] [seed]
+    python tests/fuzz_gpu.py [seconds] [seed] [big]     ("big": SRS lengths 2^13 .. 2^17 instead of 1 .. 6000)
 Random SRS secrets (degenerate ones included: 0, 1, r-1, small order-revealing values), random lengths, random
 coefficient distributions chosen to hit the rare branches (equal points -> doubling inside the mixed addition,
 P + (-P), infinity in the table, one-bucket inputs, zero-heavy inputs), commit / open / quotient / batch entry
@@ -51,6 +51,7 @@ def gen_coeffs(rnd, n):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 20261004
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
     rnd = random.Random(seed)
     t_end = time.time() + budget
     stats = {"engines": 0, "commits": 0, "opens": 0, "batches": 0, "errors_expected": 0}
@@ -59,6 +60,8 @@ def main():
         s = {"random": rnd.randrange(R), "zero": 0, "one": 1, "minus_one": R - 1, "two": 2}[sk]
         secret = s.to_bytes(32, "big")
         srs_n = rnd.choice([1, 2, 3, 5, 17, 64, 65, 255, 256, 257, 1000, 2049, 4097, rnd.randrange(1, 6000)])
+        if big:
+            srs_n = rnd.choice([1 << 13, (1 << 14) + 1, 40009, (1 << 16) + 1, rnd.randrange(1 << 13, 1 << 17)])
         if rnd.random() < 0.25:
             os.environ["KZG_MSM_RECODE"] = "naf"
         else:
