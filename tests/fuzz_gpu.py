@@ -55,7 +55,11 @@ def main():
     rnd = random.Random(seed)
     t_end = time.time() + budget
     stats = {"engines": 0, "commits": 0, "opens": 0, "batches": 0, "errors_expected": 0}
+    t_report = time.time() + 30
     while time.time() < t_end:
+        if time.time() >= t_report:  # a silent GPU job is taken for hung
+            print("fuzz progress", stats, flush=True)
+            t_report = time.time() + 30
         sk = rnd.choice(["random"] * 6 + ["zero", "one", "minus_one", "two"])
         s = {"random": rnd.randrange(R), "zero": 0, "one": 1, "minus_one": R - 1, "two": 2}[sk]
         secret = s.to_bytes(32, "big")
