@@ -167,7 +167,7 @@ int kzg_g1_uncompress(const uint8_t in[48], uint64_t out_p1[18]);
  *     e(proof, [s]G2 - [z]G2) == e(commitment - [y]G1, G2)
  * commitment, proof: blst_p1; z = evaluation.point, y = evaluation.result: blst_fr (Montgomery);
  * s_g2 = setup_artifacts[1].g2: blst_p2 (36 x u64: Jacobian x, y, z in Fp2, Montgomery).  Host only (two
- * pairings, ~60 ms: a plain restatement, not a tuned one); *valid = 1 accepted, 0 rejected.  KZG_ERR_INVALID_ARG
+ * pairings, ~35 ms: a plain restatement, not a tuned one); *valid = 1 accepted, 0 rejected.  KZG_ERR_INVALID_ARG
  * when s_g2 is not on the curve.  Next-row component. */
 int kzg_verify_proof(const uint64_t commitment_p1[18], const uint64_t proof_p1[18], const uint64_t z[4],
                      const uint64_t y[4], const uint64_t s_g2_p2[36], int* valid);
