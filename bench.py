@@ -312,7 +312,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_bucket_accumulate", "avg_kernel_ms": avg_accum_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "integer-multiply (VALU) bound by construction: see valu"},
+                         "note": "bound by integer VALU issue, not by HBM, by construction: see valu"},
             "valu": {"achieved_Tmad_s": tmad, "peak_Tmad_s": VALU_MAD_PEAK_T, "frac": tmad / VALU_MAD_PEAK_T,
                      "unit": "1e12 v_mad_u64_u32/s", "mixed_additions_per_launch": madds,
                      # time the kernel's own VALU instruction mix needs if the SIMDs issued back to back
