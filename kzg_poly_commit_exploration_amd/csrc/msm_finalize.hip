@@ -20,6 +20,7 @@
 namespace kzg {
 
 constexpr uint32_t kSerialSpan = 16;  // buckets spanning more segments than this go through the tree kernel
+constexpr uint32_t kSerialSpanFew = 4, kFewBuckets = 2048;  // threshold when there are at most kFewBuckets buckets
 constexpr int kChunk = 64;           // pieces per tree = lanes per workgroup of the tree passes
 constexpr int kTreeGrid = 2048;      // workgroups per tree pass (grid-stride over the work items)
 
@@ -109,7 +110,10 @@ __global__ void __launch_bounds__(64) k_bucket_finalize(const uint32_t* __restri
     if (l_lo == l_hi) return;  // inside one segment: written complete by k_bucket_accumulate
     const uint32_t span = l_hi - l_lo + 1;
     const bool first_is_b = s != l_lo * L;
-    if (span > kSerialSpan) {
+    // few buckets (small commitments, latency-bound): a 64-wide tree of 14 pieces is 4 dependent additions, the serial
+    // loop 13; with many buckets the serial loops run side by side and the tree kernel would need several rounds
+    const uint32_t serial_span = nb <= kFewBuckets ? kSerialSpanFew : kSerialSpan;
+    if (span > serial_span) {
         HeavyEntry en;
         en.bucket = b; en.l_lo = l_lo; en.span = span; en.first_is_b = first_is_b ? 1u : 0u;
         en.c1 = (span + kChunk - 1) / kChunk;
