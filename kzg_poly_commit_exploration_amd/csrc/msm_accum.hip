@@ -147,7 +147,8 @@ uint32_t accumulate_lanes(uint64_t max_refs) {
         uint64_t l = v ? std::strtoull(v, nullptr, 10) : 196608ull;
         return l < 64 ? 262144ull : (l > 262144ull ? 262144ull : l);
     }();
-    uint64_t lanes = (max_refs + 7) / 8;  // segments are at least 8 references long
+    const uint64_t lo = accumulate_min_seg(max_refs);
+    uint64_t lanes = (max_refs + lo - 1) / lo;  // segments are at least 8 (tiny jobs: 4) references long
     if (lanes > target) lanes = target;
     lanes = (lanes + kAccumBlock - 1) / kAccumBlock * kAccumBlock;
     return (uint32_t)lanes;
