@@ -300,7 +300,9 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 1], st));
         HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 2], st));
     }
-    const uint32_t lanes = accumulate_lanes((uint64_t)n * cfg.max_digits * batch);
+    bool alone = true;  // (this slot is still marked idle while its job is being enqueued)
+    for (const auto& other : ctx->slots) alone = alone && (&other == &s || other.kind == SLOT_IDLE);
+    const uint32_t lanes = accumulate_lanes((uint64_t)n * cfg.max_digits * batch, alone);
     HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)nbt * kXyzzBytes, st));  // zero = infinity
     HIP_TRY(ctx, hipMemsetAsync(s.d_heavy_ws, 0, 32, st));                        // long-bucket counters
     // hand over to the shared accumulation stream and back

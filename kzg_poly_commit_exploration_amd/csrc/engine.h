@@ -68,7 +68,8 @@ void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_ar
 // bucket accumulation (dominant kernel): one lane per segment of L sorted references
 constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on accumulate_lanes()
 // lanes (= segments) for at most max_refs references; a multiple of the workgroup size
-uint32_t accumulate_lanes(uint64_t max_refs);
+// alone: no other job is in flight on the context (the light kernels of other slots need no room)
+uint32_t accumulate_lanes(uint64_t max_refs, bool alone = false);
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
                               uint32_t nb, uint32_t lanes, void* d_buckets /* pre-zeroed */,
                               void* d_part_a, void* d_part_b, uint32_t lds_reserve_bytes);

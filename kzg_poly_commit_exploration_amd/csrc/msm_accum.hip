@@ -137,11 +137,12 @@ __global__ void __launch_bounds__(kAccumBlock) k_bucket_accumulate(const uint4* 
     store_xyzz(dst, acc);
 }
 
-uint32_t accumulate_lanes(uint64_t max_refs) {
+uint32_t accumulate_lanes(uint64_t max_refs, bool alone) {
     // 196608 segments = 768 workgroups.  At 206 VGPRs two workgroups are resident per CU (512 at once); the
     // last 256 start as the first ones retire and then run with the SIMDs half empty, i.e. faster per wave.
     // Measured at 2^20 terms: 196608 lanes 3.16 ms, 131072 lanes (exactly one resident round) 3.21 ms,
-    // 262144 lanes slower again.  KZG_ACCUM_LANES overrides for experiments.
+    // 262144 lanes (two full rounds) are best ALONE (2.88 ms) and worst beside other slots' kernels (277 /s): see `alone`.
+    // KZG_ACCUM_LANES overrides for experiments.
     static const uint64_t target = [] {
         const char* v = std::getenv("KZG_ACCUM_LANES");
         uint64_t l = v ? std::strtoull(v, nullptr, 10) : 196608ull;
@@ -149,7 +150,9 @@ uint32_t accumulate_lanes(uint64_t max_refs) {
     }();
     const uint64_t lo = accumulate_min_seg(max_refs);
     uint64_t lanes = (max_refs + lo - 1) / lo;  // segments are at least 8 (tiny jobs: 4) references long
-    if (lanes > target) lanes = target;
+    // alone on the chip (no other slot in flight) two full rounds are best: 2.88 instead of 2.96 ms at 2^20 terms
+    const uint64_t cap = (alone && target == 196608ull) ? 262144ull : target;
+    if (lanes > cap) lanes = cap;
     lanes = (lanes + kAccumBlock - 1) / kAccumBlock * kAccumBlock;
     return (uint32_t)lanes;
 }
