@@ -319,10 +319,9 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         HIP_TRY(ctx, hipEventRecord(s.accum_ev, hs));
         HIP_TRY(ctx, hipStreamWaitEvent(st, s.accum_ev, 0));
     }
-    launch_bucket_finalize(st, s.d_offs, nbt, lanes, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_ws);
-    HIP_TRY(ctx, hipMemcpyAsync(s.d_small + 26, s.d_offs + nbt, 4, hipMemcpyDeviceToDevice, st));  // references
+    launch_bucket_finalize(st, s.d_offs, nbt, lanes, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_ws, s.d_small + 26);
     // (gating the finalisation as well measured 3-5 % slower: it is short and wants to run at once)
-    if (ctx->gate_lds_bytes) hipLaunchKernelGGL(k_reduce_gate, dim3(1), dim3(64), ctx->gate_lds_bytes, st, (uint32_t*)nullptr);
+    if (ctx->gate_lds_bytes && !alone) hipLaunchKernelGGL(k_reduce_gate, dim3(1), dim3(64), ctx->gate_lds_bytes, st, (uint32_t*)nullptr);
     // reduction: Row / Col tree sums of every polynomial's bucket matrix, each split once more.
     // Vectors are polynomial-major ([p][index]); the final buffer holds four sections [p][len_k].
     {

@@ -79,7 +79,8 @@ void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t
 // and this launch (a fill kernel there lets the next slot's accumulation take the chip first: +0.9 ms)
 size_t heavy_workspace_bytes();
 void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t lanes, const void* d_part_a,
-                            const void* d_part_b, void* d_buckets, void* d_heavy_ws);
+                            const void* d_part_b, void* d_buckets, void* d_heavy_ws,
+                            uint32_t* d_refs_out /* receives the number of references, may be null */);
 // out[g] = sum_{q<len} in[g*gstride + q*estride], XYZZ records: log-depth tree per group;
 // up to four independent jobs per launch
 // group g reads in[(g / inner) * ostride + (g % inner) * gstride + q * estride], q < len

@@ -100,8 +100,10 @@ KZG_DEV XYZZ load_xyzz(const uint4* __restrict__ in) {
 __global__ void __launch_bounds__(64) k_bucket_finalize(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t lanes,
                                                         const uint4* __restrict__ part_a,
                                                         const uint4* __restrict__ part_b,
-                                                        uint4* __restrict__ buckets, HeavyWs ws) {
+                                                        uint4* __restrict__ buckets, HeavyWs ws,
+                                                        uint32_t* __restrict__ refs_out) {
     uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0 && refs_out) refs_out[0] = offs[nb];  // number of references, for the host's statistics
     if (b >= nb) return;
     const uint32_t L = accumulate_seg_len(offs[nb], lanes);
     uint32_t s = offs[b], e = offs[b + 1];
@@ -232,12 +234,12 @@ __global__ void __launch_bounds__(kChunk) k_heavy_tree(const uint4* __restrict__
 }
 
 void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t lanes, const void* d_part_a,
-                            const void* d_part_b, void* d_buckets, void* d_heavy_ws) {
+                            const void* d_part_b, void* d_buckets, void* d_heavy_ws, uint32_t* d_refs_out) {
     HeavyWs ws = carve(d_heavy_ws);
     const uint4* pa = reinterpret_cast<const uint4*>(d_part_a);
     const uint4* pb = reinterpret_cast<const uint4*>(d_part_b);
     uint4* bk = reinterpret_cast<uint4*>(d_buckets);
-    hipLaunchKernelGGL(k_bucket_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, d_offs, nb, lanes, pa, pb, bk, ws);
+    hipLaunchKernelGGL(k_bucket_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, d_offs, nb, lanes, pa, pb, bk, ws, d_refs_out);
     hipLaunchKernelGGL(k_heavy_tree, dim3(kTreeGrid), dim3(kChunk), 0, s, pa, pb, bk, ws);
 }
 
