@@ -28,6 +28,10 @@ namespace hf = kzg_host;
 
 namespace {
 
+// The reference refuses polynomials of more than u32::MAX coefficients (src/polynomial.rs:56-61); the kernels index
+// with 32 bits, so the C-ABI refuses them too instead of truncating the count.
+constexpr size_t kMaxCoefficients = 0xFFFFFFFFull;
+
 constexpr int kNumSlots = 3;  // + the shared accumulation stream = the 4 hardware queues HIP gives a process by default
 // Reduction plan (msm_reduce.hip): bucket index b = hi * C + lo; Row (R entries) and Col (C entries)
 // are each split once more into a "row" part and a "column" part that the host receives.
@@ -39,7 +43,9 @@ struct ReducePlan {
     uint32_t off_r2row = 0, off_c2row = 0, off_r2col = 0, off_c2col = 0, total = 0;
 };
 
-enum SlotKind { SLOT_IDLE = 0, SLOT_COMMIT = 1, SLOT_OPEN = 2, SLOT_TRIVIAL = 3 };
+// what a slot holds decides which wait entry point may collect it (a batched job's final buffer is laid out
+// [section][polynomial][record]; reading it as a single job would return a wrong point with KZG_OK)
+enum SlotKind { SLOT_IDLE = 0, SLOT_COMMIT = 1, SLOT_OPEN = 2, SLOT_TRIVIAL = 3, SLOT_COMMIT_BATCH = 4, SLOT_OPEN_BATCH = 5 };
 
 struct Slot {
     hipStream_t stream = nullptr;
@@ -202,8 +208,33 @@ void plan_reduce(kzg_ctx* ctx) {
     ctx->final_records = P.total;
 }
 
-int setup_slots(kzg_ctx* ctx) {
+int setup_slots_impl(kzg_ctx* ctx);
+// (Re)allocates every slot's MSM workspace.  On any failure the context is left WITHOUT an SRS (n = 0, no
+// workspaces, slots_ready false): the next commit returns KZG_ERR_NO_SRS instead of launching on freed buffers.
+int setup_slots(kzg_ctx* ctx, bool keep_table_on_failure = false) {
+    ctx->slots_ready = false;
+    int rc = setup_slots_impl(ctx);
+    if (rc != KZG_OK) {
+        for (auto& s : ctx->slots) free_slot_msm(s);
+        if (keep_table_on_failure) return rc;  // the caller retries with the previous sizes
+        if (ctx->d_table) {
+            hipFree(ctx->d_table);
+            ctx->d_table = nullptr;
+        }
+        ctx->n = 0;
+        (void)hipGetLastError();
+    }
+    return rc;
+}
+int setup_slots_impl(kzg_ctx* ctx) {
     plan_reduce(ctx);
+    if (const char* v = std::getenv("KZG_TEST_FAIL_SLOT_ALLOC")) {  // fault injection for tests/test_gpu_parity.py
+        const int mode = std::atoi(v);  // 1: every setup fails; 2: only setups for more than one polynomial per batch
+        if (mode == 1 || (mode == 2 && ctx->max_batch > 1)) {
+            ctx->last_error = "injected allocation failure (KZG_TEST_FAIL_SLOT_ALLOC)";
+            return KZG_ERR_HIP;
+        }
+    }
     if (!ctx->heavy_stream) {
         int least = 0, greatest = 0;
         HIP_TRY(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -266,6 +297,7 @@ int drain_all(kzg_ctx* ctx) {
 
 int srs_prepare(kzg_ctx* ctx, size_t n) {
     if (n == 0 || n > 0x7fffffffu / 32) return KZG_ERR_INVALID_ARG;
+    ctx->slots_ready = false;
     int rc = drain_all(ctx);
     if (rc) return rc;
     for (auto& s : ctx->slots) s.kind = SLOT_IDLE;
@@ -605,6 +637,7 @@ static int submit_commit_locked(kzg_ctx* ctx, int slot, const uint32_t* d_scalar
 
 int kzg_commit_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n) {
     if (!ctx || (!d_coeffs && n)) return KZG_ERR_INVALID_ARG;
+    if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     return submit_commit_locked(ctx, slot, (const uint32_t*)d_coeffs, 1, n, false);
 }
@@ -657,6 +690,7 @@ static int submit_open_locked(kzg_ctx* ctx, int slot, const uint32_t* d_coeffs, 
 
 int kzg_open_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, const uint64_t z[4], const uint64_t y[4]) {
     if (!ctx || !z || !y || (!d_coeffs && n)) return KZG_ERR_INVALID_ARG;
+    if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     return submit_open_locked(ctx, slot, (const uint32_t*)d_coeffs, n, z, y);
 }
@@ -665,6 +699,10 @@ static int wait_locked(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
     if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
     Slot& s = ctx->slots[slot];
     if (s.kind == SLOT_IDLE) return KZG_ERR_INVALID_ARG;
+    if (s.kind == SLOT_COMMIT_BATCH || s.kind == SLOT_OPEN_BATCH) {
+        ctx->last_error = "kzg_wait on a slot that holds a batched job (use kzg_wait_batch / kzg_wait_open_batch)";
+        return KZG_ERR_INVALID_ARG;  // the job stays in the slot
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     SlotKind kind = s.kind;
     s.kind = SLOT_IDLE;
@@ -725,15 +763,26 @@ int kzg_set_max_batch(kzg_ctx* ctx, size_t max_batch) {
     if (rc) return rc;
     for (auto& s : ctx->slots)
         if (s.kind != SLOT_IDLE) return KZG_ERR_BUSY;
+    const uint32_t previous = ctx->max_batch;
     ctx->max_batch = (uint32_t)(max_batch > 1024 ? 1024 : max_batch);
-    return ctx->n ? setup_slots(ctx) : KZG_OK;  // workspaces are (re)sized when an SRS is resident
+    if (!ctx->n) return KZG_OK;  // workspaces are (re)sized when an SRS is resident
+    rc = setup_slots(ctx, true);
+    if (rc != KZG_OK) {
+        // e.g. out of HBM: go back to the size that worked; if even that fails the SRS is dropped (KZG_ERR_NO_SRS next)
+        const std::string why = ctx->last_error;
+        ctx->max_batch = previous;
+        (void)hipGetLastError();
+        (void)setup_slots(ctx);
+        ctx->last_error = why;
+    }
+    return rc;
 }
 
 size_t kzg_max_batch(const kzg_ctx* ctx) { return ctx ? ctx->max_batch : 0; }
 
 int kzg_commit_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch,
                             size_t stride_coeffs) {
-    if (!ctx || !d_coeffs || n == 0 || batch == 0 || stride_coeffs < n) return KZG_ERR_INVALID_ARG;
+    if (!ctx || !d_coeffs || n == 0 || batch == 0 || stride_coeffs < n || n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
     if (slot < 0 || slot >= kNumSlots || batch > ctx->max_batch) return KZG_ERR_INVALID_ARG;
@@ -752,7 +801,7 @@ int kzg_commit_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
-    s.kind = SLOT_COMMIT;
+    s.kind = SLOT_COMMIT_BATCH;
     return KZG_OK;
 }
 
@@ -761,7 +810,7 @@ int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
     Slot& s = ctx->slots[slot];
-    if (s.kind != SLOT_COMMIT || s.has_quotient || s.job_batch != batch) return KZG_ERR_INVALID_ARG;
+    if (s.kind != SLOT_COMMIT_BATCH || s.job_batch != batch) return KZG_ERR_INVALID_ARG;  // the job stays in the slot
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     s.kind = SLOT_IDLE;
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
@@ -795,7 +844,7 @@ int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
 // ONE batched MSM over the `batch` quotients.
 int kzg_open_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch, size_t stride_coeffs,
                           const uint64_t* zs, const uint64_t* ys) {
-    if (!ctx || !d_coeffs || !zs || !ys || n < 2 || batch == 0 || stride_coeffs < n) return KZG_ERR_INVALID_ARG;
+    if (!ctx || !d_coeffs || !zs || !ys || n < 2 || batch == 0 || stride_coeffs < n || n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
     if (slot < 0 || slot >= kNumSlots || batch > ctx->max_batch) return KZG_ERR_INVALID_ARG;
@@ -839,7 +888,7 @@ int kzg_open_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n
     HIP_TRY(ctx, hipMemcpyAsync(s.h_bsmall, s.d_bsmall, batch * 32 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
-    s.kind = SLOT_OPEN;
+    s.kind = SLOT_OPEN_BATCH;
     return KZG_OK;
 }
 
@@ -848,8 +897,8 @@ int kzg_wait_open_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, int* statuses
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
     Slot& s = ctx->slots[slot];
-    if (s.kind != SLOT_OPEN || !s.has_quotient || s.job_batch != batch || s.open_ys.size() != 8 * batch)
-        return KZG_ERR_INVALID_ARG;
+    if (s.kind != SLOT_OPEN_BATCH || s.job_batch != batch || s.open_ys.size() != 8 * batch)
+        return KZG_ERR_INVALID_ARG;  // the job stays in the slot
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     s.kind = SLOT_IDLE;
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
@@ -898,6 +947,7 @@ static int find_idle_slot(kzg_ctx* ctx) {
 
 static int commit_host(kzg_ctx* ctx, const void* scalars, int is_mont, size_t n, uint64_t out_p1[18]) {
     if (!ctx || !out_p1 || (!scalars && n)) return KZG_ERR_INVALID_ARG;
+    if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
     int slot = find_idle_slot(ctx);
@@ -924,6 +974,7 @@ int kzg_commit_le_bytes(kzg_ctx* ctx, const uint8_t* scalars_le, size_t n, uint6
 int kzg_open(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4], const uint64_t y[4],
              uint64_t out_p1[18]) {
     if (!ctx || !out_p1 || !z || !y || (!coeffs && n)) return KZG_ERR_INVALID_ARG;
+    if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
     int slot = find_idle_slot(ctx);
@@ -941,6 +992,7 @@ int kzg_open(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4]
 int kzg_quotient(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4], const uint64_t y[4],
                  uint64_t* out_q, size_t* out_qn) {
     if (!ctx || !z || !y || !out_qn || (!coeffs && n) || (!out_q && n > 1)) return KZG_ERR_INVALID_ARG;
+    if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     *out_qn = 0;
     int slot = find_idle_slot(ctx);
@@ -977,6 +1029,7 @@ int kzg_quotient(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t 
 
 int kzg_evaluate(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out_y[4]) {
     if (!ctx || !z || !out_y || (!coeffs && n)) return KZG_ERR_INVALID_ARG;
+    if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     std::memset(out_y, 0, 32);
     if (n == 0) return KZG_OK;

@@ -32,25 +32,48 @@ _BUFFERS = {}
 
 
 def _buffers(world, device, count=1):
-    """Persistent staging buffers: pinned host in/out plus device in/out (count x 18 int64 per rank)."""
+    """Persistent staging buffers: pinned host in/out plus device in/out (count x 18 int64 per rank, plus ONE
+    status word per rank: an engine error on one rank travels with the partials, so every rank leaves the
+    collective and raises the same error instead of the healthy ranks blocking in it forever)."""
     import torch
 
     key = (world, str(device), count)
     if key not in _BUFFERS:
         pin = device is not None
-        h_in = torch.empty(18 * count, dtype=torch.int64, pin_memory=pin)
-        h_out = torch.empty(18 * count * world, dtype=torch.int64, pin_memory=pin)
+        words = 18 * count + 1
+        h_in = torch.empty(words, dtype=torch.int64, pin_memory=pin)
+        h_out = torch.empty(words * world, dtype=torch.int64, pin_memory=pin)
         if device is not None:
-            d_in = torch.empty(18 * count, dtype=torch.int64, device=device)
-            d_out = torch.empty(18 * count * world, dtype=torch.int64, device=device)
+            d_in = torch.empty(words, dtype=torch.int64, device=device)
+            d_out = torch.empty(words * world, dtype=torch.int64, device=device)
         else:
             d_in, d_out = h_in, h_out
         _BUFFERS[key] = (h_in, h_out, d_in, d_out)
     return _BUFFERS[key]
 
 
-def allgather_partials(partial, device=None, group=None):
-    """All-gathers one G1Point (144 B) per rank through torch.distributed, rank order preserved.
+def _raise_first_failure(statuses):
+    """Same KzgError on every rank: the status of the lowest failing rank."""
+    for r, st in enumerate(statuses):
+        if st != 0:
+            raise KzgError(int(st), load_library().kzg_strerror(int(st)).decode() + " (rank %d)" % r)
+
+
+def guarded(fn):
+    """Runs a local engine call; returns (result, 0) or (None, status) instead of raising before a collective."""
+    try:
+        return fn(), 0
+    except KzgError as e:
+        return None, int(e.status)
+
+
+_INFINITY = np.zeros(18, dtype=np.uint64)
+
+
+def allgather_partials(partial, device=None, group=None, status=0):
+    """All-gathers one G1Point (144 B) and one status word per rank through torch.distributed, rank order
+    preserved.  `status` != 0 (an engine error on this rank; `partial` may then be None) makes EVERY rank raise
+    that KzgError after the collective.
 
     With `device` set the exchange runs on the GPU (backend nccl = RCCL over xGMI): one tiny H2D copy,
     one all_gather_into_tensor, one D2H copy, all on persistent buffers.  uint64 limbs travel as int64."""
@@ -59,7 +82,8 @@ def allgather_partials(partial, device=None, group=None):
 
     world = dist.get_world_size(group)
     h_in, h_out, d_in, d_out = _buffers(world, device)
-    h_in.numpy()[:] = partial.p1.view(np.int64)
+    h_in.numpy()[:18] = (_INFINITY if partial is None else partial.p1).view(np.int64)
+    h_in.numpy()[18] = status
     if device is not None:
         d_in.copy_(h_in, non_blocking=True)
         dist.all_gather_into_tensor(d_out, d_in, group=group)
@@ -69,20 +93,26 @@ def allgather_partials(partial, device=None, group=None):
         gathered = [torch.empty_like(h_in) for _ in range(world)]
         dist.all_gather(gathered, h_in, group=group)
         h_out.copy_(torch.cat(gathered))
-    arr = h_out.numpy().view(np.uint64).reshape(world, 18)
+    raw = h_out.numpy().reshape(world, 19)
+    _raise_first_failure(raw[:, 18])
+    arr = raw[:, :18].copy().view(np.uint64)
     return [G1Point(arr[r].copy()) for r in range(world)]
 
 
-def allgather_partial_batch(partials, device=None, group=None):
+def allgather_partial_batch(partials, device=None, group=None, status=0, count=None):
     """Batch form: `partials` = this rank's list of B G1Points; returns B lists of `world` points
-    (one exchange of B x 144 bytes per rank)."""
+    (one exchange of B x 144 bytes + one status word per rank).  With status != 0 pass count=B and partials=None."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    count = len(partials)
+    count = len(partials) if count is None else count
     h_in, h_out, d_in, d_out = _buffers(world, device, count)
-    h_in.numpy().reshape(count, 18)[:] = np.stack([p.p1 for p in partials]).view(np.int64)
+    if status == 0:
+        h_in.numpy()[:18 * count].reshape(count, 18)[:] = np.stack([p.p1 for p in partials]).view(np.int64)
+    else:
+        h_in.numpy()[:18 * count] = 0
+    h_in.numpy()[18 * count] = status
     if device is not None:
         d_in.copy_(h_in, non_blocking=True)
         dist.all_gather_into_tensor(d_out, d_in, group=group)
@@ -92,7 +122,9 @@ def allgather_partial_batch(partials, device=None, group=None):
         gathered = [torch.empty_like(h_in) for _ in range(world)]
         dist.all_gather(gathered, h_in, group=group)
         h_out.copy_(torch.cat(gathered))
-    arr = h_out.numpy().view(np.uint64).reshape(world, count, 18)
+    raw = h_out.numpy().reshape(world, 18 * count + 1)
+    _raise_first_failure(raw[:, 18 * count])
+    arr = raw[:, :18 * count].copy().view(np.uint64).reshape(world, count, 18)
     return [[G1Point(arr[r, b].copy()) for r in range(world)] for b in range(count)]
 
 
@@ -102,9 +134,10 @@ def combine(partials):
 
 
 def sharded_commit(engine, coeff_slice_limbs, device=None, group=None):
-    """Commit this rank's coefficient slice on its SRS slice and reduce across ranks."""
-    partial = engine.commit_limbs(coeff_slice_limbs)
-    return combine(allgather_partials(partial, device=device, group=group))
+    """Commit this rank's coefficient slice on its SRS slice and reduce across ranks.  An engine error on any rank
+    (degree too high for its slice, HIP error, busy slot) is raised on every rank, after the collective."""
+    partial, status = guarded(lambda: engine.commit_limbs(coeff_slice_limbs))
+    return combine(allgather_partials(partial, device=device, group=group, status=status))
 
 
 def _allgather_u64(vec, world_group=None, device=None):
@@ -148,11 +181,15 @@ def sharded_open(engine, coeff_slice_limbs, z, y, device=None, group=None):
 
     rank = dist.get_rank(group)
     sl = np.ascontiguousarray(coeff_slice_limbs, dtype=np.uint64).reshape(-1, 4)
-    h = engine.evaluate_limbs(sl, z) if len(sl) else Scalar(0)
+    h, h_status = guarded(lambda: engine.evaluate_limbs(sl, z)) if len(sl) else (Scalar(0), 0)
+    if h is None:
+        h = Scalar(0)
     first = 1 if rank == 0 else 0  # index 0 of the polynomial is not a "higher" coefficient
     higher = int(sl[first:].any()) if len(sl) > first else 0
     c0 = sl[0] if (rank == 0 and len(sl)) else np.zeros(4, dtype=np.uint64)
-    gathered = _allgather_u64(np.concatenate([h.limbs(), [np.uint64(len(sl)), np.uint64(higher)], c0]), group, device)
+    gathered = _allgather_u64(np.concatenate([h.limbs(), [np.uint64(len(sl)), np.uint64(higher)], c0,
+                                              [np.uint64(h_status & 0xFFFFFFFF)]]), group, device)
+    _raise_first_failure([int(np.int32(np.uint32(int(g[10])))) for g in gathered])  # an engine error of the evaluation, on every rank
     hs = [Scalar.from_limbs(g[:4]).v for g in gathered]
     lens = [int(g[4]) for g in gathered]
     any_higher = any(int(g[5]) for g in gathered)
@@ -166,7 +203,7 @@ def sharded_open(engine, coeff_slice_limbs, z, y, device=None, group=None):
     if starts[0] != y.v:  # P(z) != y (src/polynomial.rs:184-192)
         raise KzgError(KZG_ERR_REMAINDER, lib.kzg_strerror(KZG_ERR_REMAINDER).decode())
     if len(sl):
-        partial = sharded_open_local(engine, sl, carries[rank], z, starts[rank])
+        partial, status = guarded(lambda: sharded_open_local(engine, sl, carries[rank], z, starts[rank]))
     else:
-        partial = G1Point(np.zeros(18, dtype=np.uint64))
-    return combine(allgather_partials(partial, device=device, group=group))
+        partial, status = G1Point(np.zeros(18, dtype=np.uint64)), 0
+    return combine(allgather_partials(partial, device=device, group=group, status=status))

@@ -1,0 +1,93 @@
+// Host build of csrc/field30.hip.h for tests/test_field30.py (plain g++; the header is __host__ __device__ code).
+// Test infrastructure only.  Exposes the digit-level routines over a C ABI and a variant of the multiplier that
+// reports the largest column magnitude (to check the "fits a signed 64-bit accumulator" contract).
+#include <stdint.h>
+#include <string.h>
+
+#include "../../kzg_poly_commit_exploration_amd/csrc/field30.hip.h"
+
+using namespace kzg;
+
+extern "C" {
+
+void f30_mul(const int32_t* a, const int32_t* b, int32_t* r) {
+    Fq x, y;
+    memcpy(x.d, a, sizeof x.d);
+    memcpy(y.d, b, sizeof y.d);
+    Fq z = fq_mul(x, y);
+    memcpy(r, z.d, sizeof z.d);
+}
+void f30_sqr(const int32_t* a, int32_t* r) {
+    Fq x;
+    memcpy(x.d, a, sizeof x.d);
+    Fq z = fq_sqr(x);
+    memcpy(r, z.d, sizeof z.d);
+}
+void f30_norm(const int32_t* a, int32_t* r) {
+    Fq x;
+    memcpy(x.d, a, sizeof x.d);
+    Fq z = fq_norm(x);
+    memcpy(r, z.d, sizeof z.d);
+}
+int f30_is_zero(const int32_t* a) {
+    Fq x;
+    memcpy(x.d, a, sizeof x.d);
+    return fq_is_zero(x) ? 1 : 0;
+}
+void f30_from_u32x12(const uint32_t* s, int32_t* r) {
+    Fq z = fq_from_u32x12(s);
+    memcpy(r, z.d, sizeof z.d);
+}
+void f30_to_u32x12(const int32_t* a, uint32_t* out) {
+    Fq x;
+    memcpy(x.d, a, sizeof x.d);
+    fq_to_u32x12(x, out);
+}
+
+// the multiplier's column sums in exact arithmetic (__int128): returns the largest |column| / 2^48 seen
+int64_t f30_mul_max_column(const int32_t* a, const int32_t* b) {
+    int32_t m[13];
+    __int128 acc = 0, worst = 0;
+    auto track = [&](__int128 v) {
+        if (v < 0) v = -v;
+        if (v > worst) worst = v;
+    };
+    for (int k = 0; k < 13; k++) {
+        // worst case inside the column: sum of magnitudes
+        __int128 mag = acc < 0 ? -acc : acc;
+        for (int i = 0; i <= k; i++) {
+            __int128 t = (__int128)a[i] * b[k - i];
+            acc += t;
+            mag += t < 0 ? -t : t;
+        }
+        for (int j = 0; j < k; j++) {
+            __int128 t = (__int128)m[j] * fq_pd(k - j);
+            acc += t;
+            mag += t < 0 ? -t : t;
+        }
+        m[k] = fq_sext30((uint32_t)(uint64_t)acc * kQN0);
+        __int128 t = (__int128)m[k] * fq_pd(0);
+        acc += t;
+        mag += t < 0 ? -t : t;
+        track(mag);
+        acc >>= 30;
+    }
+    for (int k = 13; k < 25; k++) {
+        __int128 mag = acc < 0 ? -acc : acc;
+        for (int i = k - 12; i < 13; i++) {
+            __int128 t = (__int128)a[i] * b[k - i];
+            acc += t;
+            mag += t < 0 ? -t : t;
+        }
+        for (int j = k - 12; j < 13; j++) {
+            __int128 t = (__int128)m[j] * fq_pd(k - j);
+            acc += t;
+            mag += t < 0 ? -t : t;
+        }
+        track(mag);
+        int32_t dgt = fq_sext30((uint32_t)(uint64_t)acc);
+        acc = (acc - dgt) >> 30;
+    }
+    return (int64_t)(worst >> 48);
+}
+}

@@ -130,6 +130,85 @@ def test_two_rank_sharded_opening_over_gloo(golden):
         assert wrong == -3  # KZG_ERR_REMAINDER on every rank
 
 
+def _failing_worker(rank, world, port, n, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+
+    import bigint_twin as T
+    import kzg_poly_commit_exploration_amd as K
+    import oracle_ctypes as O
+    from kzg_poly_commit_exploration_amd import sharding
+
+    class Engine:
+        """Oracle stand-in whose rank-1 instance fails like a GPU engine would (degree too high / busy slot)."""
+
+        def __init__(self, srs, fail_with):
+            self.srs, self.fail_with = srs, fail_with
+
+        def commit_limbs(self, c):
+            if self.fail_with:
+                raise K.KzgError(self.fail_with, "injected")
+            rc, p = O.commit_naive(c, self.srs)
+            assert rc == 0
+            return K.G1Point(p)
+
+        def evaluate_limbs(self, c, z):
+            return K.Scalar.from_limbs(O.poly_evaluate(c, O.fr_from_int(z.v)))
+
+        def open_limbs(self, c, z, y):
+            if self.fail_with:
+                raise K.KzgError(self.fail_with, "injected")
+            rc, pf = O.generate_proof(c, O.fr_from_int(z.v), O.fr_from_int(y.v), self.srs)
+            assert rc == 0
+            return K.G1Point(pf)
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = sharding.shard_range(n, rank, world)
+        srs = np.stack([O.srs_g1_at(k, T.BENCH_SECRET_BE) for k in range(lo, hi)])
+        c = O.bench_coefficients(n)
+        z = K.Scalar(T.bench_input_point(n - 1))
+        y = K.Scalar.from_limbs(O.poly_evaluate(c, O.fr_from_int(z.v)))
+        eng = Engine(srs, K.KZG_ERR_BUSY if rank == 1 else 0)
+        seen = []
+        for call in (lambda: sharding.sharded_commit(eng, c[lo:hi]), lambda: sharding.sharded_open(eng, c[lo:hi], z, y)):
+            try:
+                call()
+                seen.append("ok")
+            except K.KzgError as e:
+                seen.append(e.status)
+        # the group is still usable afterwards: a healthy collective completes on both ranks
+        ok = sharding.sharded_commit(Engine(srs, 0), c[lo:hi]).compress().hex()
+        out_q.put((rank, seen, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_engine_error_on_one_rank_is_raised_on_every_rank(golden):
+    """a KzgError raised on one rank before the all-gather left the other ranks blocked in the collective.
+    The status now travels with the partials; both ranks raise the failing rank's error and nobody hangs."""
+    import torch.multiprocessing as mp
+
+    n = 101
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = next(b["commit"] for b in golden["bench"] if b["degree"] == n - 1)
+    for _, seen, ok in got:
+        assert seen == [-8, -8]  # KZG_ERR_BUSY from rank 1, on both ranks, for commit and for open
+        assert ok == want
+
+
 def test_shard_ranges_cover_everything():
     sys.path.insert(0, ROOT)
     from kzg_poly_commit_exploration_amd.sharding import shard_range

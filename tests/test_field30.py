@@ -1,0 +1,162 @@
+"""Host-side checks of csrc/field30.hip.h (signed radix-2^30 Fp, the arithmetic of the accumulation kernel) against
+Python big integers: products, squares, the conversion to and from the library's 12 x u32 storage format, the zero
+test, and the contract that every column of the multiplier fits a signed 64-bit accumulator at the digit sizes the
+group law feeds it.  CPU only: the header is __host__ __device__ code, compiled here with g++."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+B, N = 30, 13
+RQ = 1 << 390
+R384 = 1 << 384
+I13 = ctypes.c_int32 * 13
+U12 = ctypes.c_uint32 * 12
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("f30") / "libf30.so")
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", out, os.path.join(ROOT, "tests", "host", "field30_host.cpp")],
+                   check=True)
+    L = ctypes.CDLL(out)
+    L.f30_mul_max_column.restype = ctypes.c_int64
+    return L
+
+
+def balanced(v):
+    d = []
+    for _ in range(N - 1):
+        r = v & ((1 << B) - 1)
+        if r >= 1 << (B - 1):
+            r -= 1 << B
+        d.append(r)
+        v = (v - r) >> B
+    d.append(v)
+    assert -(1 << 31) <= v < (1 << 31)
+    return d
+
+
+def value(d):
+    return sum(int(x) << (B * i) for i, x in enumerate(d))
+
+
+def rand_lazy(rng, bound_bits=383):
+    """a lazy representative: any integer of magnitude < 2^bound_bits"""
+    return rng.randrange(-(1 << bound_bits), 1 << bound_bits)
+
+
+def mul(lib, a, b):
+    r = I13()
+    lib.f30_mul(I13(*a), I13(*b), r)
+    return list(r)
+
+
+def test_constants():
+    pd = balanced(P)
+    assert value(pd) == P
+    assert (P * 0x3ffcfffd + 1) % (1 << B) == 0
+
+
+def test_mul_and_sqr_random(lib):
+    rng = random.Random(30)
+    for it in range(3000):
+        a, b = rand_lazy(rng), rand_lazy(rng)
+        da, db = balanced(a), balanced(b)
+        r = mul(lib, da, db)
+        v = value(r)
+        assert (v * RQ - a * b) % P == 0
+        assert abs(v) < 0.62 * P + (abs(a) * abs(b) >> 390) + 1
+        assert all(-(1 << 29) <= x < (1 << 29) for x in r[:12])
+        s = I13()
+        lib.f30_sqr(I13(*da), s)
+        assert (value(list(s)) * RQ - a * a) % P == 0
+        assert all(-(1 << 29) <= x < (1 << 29) for x in list(s)[:12])
+
+
+def test_mul_accepts_a_raw_sum(lib):
+    """one operand may be the digit-wise sum or difference of two normalised values (group law: R * (Q - X3))"""
+    rng = random.Random(31)
+    worst = 0
+    for it in range(2000):
+        x, y, z = (balanced(rand_lazy(rng, 381)) for _ in range(3))
+        raw = [p - q if it & 1 else p + q for p, q in zip(x, y)]
+        r = mul(lib, raw, z)
+        assert (value(r) * RQ - value(raw) * value(z)) % P == 0
+        worst = max(worst, lib.f30_mul_max_column(I13(*raw), I13(*z)))
+    assert worst < (1 << 15)  # |column| < 2^63
+
+
+def test_column_bound_adversarial(lib):
+    """all digits at the extreme of the contract, every sign pattern that makes the terms of a column add up"""
+    big = (1 << 29) + 4
+    for sa in (1, -1):
+        for sb in (1, -1):
+            a = [sa * 2 * big] * 12 + [1 << 27]  # raw sum of two weakly normalised values
+            b = [sb * big] * 12 + [1 << 27]
+            assert lib.f30_mul_max_column(I13(*a), I13(*b)) < (1 << 15)
+            r = mul(lib, a, b)
+            assert (value(r) * RQ - value(a) * value(b)) % P == 0
+    # digits alternating in sign the way p's digits do (maximises the m*p part)
+    pd = balanced(P)
+    a = [(2 * big if x >= 0 else -2 * big) for x in pd[:12]] + [0]
+    b = [big] * 12 + [0]
+    assert lib.f30_mul_max_column(I13(*a), I13(*b)) < (1 << 15)
+
+
+def test_norm(lib):
+    rng = random.Random(32)
+    for it in range(2000):
+        d = [rng.randrange(-(3 << 29), 3 << 29) for _ in range(12)] + [rng.randrange(-(1 << 26), 1 << 26)]
+        r = I13()
+        lib.f30_norm(I13(*d), r)
+        r = list(r)
+        assert value(r) == value(d)
+        assert all(abs(x) <= (1 << 29) + 4 for x in r[:12])
+
+
+def test_is_zero(lib):
+    rng = random.Random(33)
+    for k in range(-3, 4):
+        d = balanced(k * P)
+        # an un-normalised spelling of the same integer
+        e = list(d)
+        e[3] += 1 << 30
+        e[4] -= 1
+        assert lib.f30_is_zero(I13(*d)) == 1
+        assert lib.f30_is_zero(I13(*e)) == 1
+    for it in range(2000):
+        v = rand_lazy(rng, 382)
+        assert lib.f30_is_zero(I13(*balanced(v))) == (1 if v % P == 0 else 0)
+    # same low digit as p, different integer
+    d = balanced(P)
+    d[5] += 1
+    assert lib.f30_is_zero(I13(*d)) == 0
+
+
+def test_storage_round_trip(lib):
+    """12 x u32 Montgomery (R = 2^384, value in [0, 2p)) -> signed digits (R' = 2^390) -> back, canonical"""
+    rng = random.Random(34)
+    for it in range(2000):
+        x = rng.randrange(P)
+        s = (x * R384) % P
+        if it & 1:
+            s += P  # the lazily reduced second representative
+        if it == 0:
+            s = 0
+        if it == 1:
+            s = P
+        words = [(s >> (32 * i)) & 0xffffffff for i in range(12)]
+        d = I13()
+        lib.f30_from_u32x12(U12(*words), d)
+        v = value(list(d))
+        assert v == 64 * s
+        assert all(abs(t) <= (1 << 29) for t in list(d)[:12])
+        out = U12()
+        lib.f30_to_u32x12(d, out)
+        back = sum(int(w) << (32 * i) for i, w in enumerate(out))
+        assert back == s % P

@@ -604,6 +604,94 @@ def test_pipelined_slots_device_resident(engines, oracle, golden):
         eng.dev_free(dptr)
 
 
+def test_wait_entry_points_reject_the_wrong_job_kind(oracle, golden):
+    """A slot filled by a batched submit must be collected by the batched wait and vice versa: the final buffer of a
+    batch is laid out [section][polynomial], reading it as a single job would return a wrong point with KZG_OK.
+    A rejected wait leaves the job in the slot; the right wait then returns the right answer."""
+    secret = bytes.fromhex(golden["secret_be"])
+    n = 1500
+    eng = K.SetupArtifactsGenerator(secret).take(n)
+    try:
+        assert eng.set_max_batch(2) == 2
+        rnd = random.Random(5)
+        polys = [K.scalars_to_limbs([rnd.randrange(K.R_MODULUS) for _ in range(n)]) for _ in range(2)]
+        want = [eng.commit_limbs(p).compress() for p in polys]
+        flat = np.concatenate(polys)
+        dptr = eng.dev_alloc(flat.nbytes)
+        try:
+            eng.dev_upload(dptr, flat)
+            # batched commit, collected with the single wait
+            eng.commit_batch_submit(0, dptr, n, 2)
+            with pytest.raises(K.KzgError) as ei:
+                eng.wait(0)
+            assert ei.value.status == K.KZG_ERR_INVALID_ARG
+            with pytest.raises(K.KzgError):
+                eng.wait_batch(0, 1)  # wrong batch size
+            assert [g.compress() for g in eng.wait_batch(0, 2)] == want
+            # single commit, collected with the batched wait
+            eng.commit_submit(1, dptr, n)
+            with pytest.raises(K.KzgError) as ei:
+                eng.wait_batch(1, 1)
+            assert ei.value.status == K.KZG_ERR_INVALID_ARG
+            assert eng.wait(1).compress() == want[0]
+            # batched opening, collected with the single wait and with the batched commit wait
+            zs = [K.Scalar(rnd.randrange(K.R_MODULUS)) for _ in polys]
+            ys = [eng.evaluate_limbs(p, z) for p, z in zip(polys, zs)]
+            zl = np.ascontiguousarray(np.stack([z.limbs() for z in zs]))
+            yl = np.ascontiguousarray(np.stack([y.limbs() for y in ys]))
+            import ctypes as C
+            lib, h = eng._lib, eng._h
+            assert lib.kzg_open_batch_submit(h, 2, C.c_void_p(dptr), n, 2, n, K._ptr(zl), K._ptr(yl)) == K.KZG_OK
+            with pytest.raises(K.KzgError):
+                eng.wait(2)
+            with pytest.raises(K.KzgError):
+                eng.wait_batch(2, 2)
+            out = np.zeros((2, 18), dtype=np.uint64)
+            st = np.zeros(2, dtype=np.int32)
+            assert lib.kzg_wait_open_batch(h, 2, K._ptr(out), K._ptr(st), 2) == K.KZG_OK
+            assert list(st) == [0, 0]
+            for i in range(2):
+                assert K.G1Point(out[i]).compress() == eng.open_limbs(polys[i], zs[i], ys[i]).compress()
+        finally:
+            eng.dev_free(dptr)
+    finally:
+        eng.close()
+
+
+def test_failed_workspace_allocation_leaves_no_half_ready_context(oracle, golden, monkeypatch):
+    """If the slot workspaces cannot be allocated the context must not keep slots_ready / n from an earlier setup:
+    the next commit answers KZG_ERR_NO_SRS (or works, when the previous sizes could be restored) -- never a launch
+    on freed buffers."""
+    secret = bytes.fromhex(golden["secret_be"])
+    n = 700
+    c = oracle.bench_coefficients(n)
+    eng = K.SetupArtifactsGenerator(secret).take(n)
+    try:
+        want = eng.commit_limbs(c).compress()
+        # (a) growing the batch fails: the previous size is restored and the engine keeps working
+        monkeypatch.setenv("KZG_TEST_FAIL_SLOT_ALLOC", "2")
+        with pytest.raises(K.KzgError) as ei:
+            eng.set_max_batch(4)
+        assert ei.value.status == K.KZG_ERR_HIP
+        assert eng.max_batch() == 1
+        assert eng.commit_limbs(c).compress() == want
+        # (b) every setup fails: loading an SRS reports the error and leaves the context without one
+        monkeypatch.setenv("KZG_TEST_FAIL_SLOT_ALLOC", "1")
+        with pytest.raises(K.KzgError) as ei:
+            eng.srs_generate(secret, n)
+        assert ei.value.status == K.KZG_ERR_HIP
+        assert eng.srs_len() == 0
+        with pytest.raises(K.KzgError) as ei:
+            eng.commit_limbs(c)
+        assert ei.value.status == K.KZG_ERR_NO_SRS
+        # (c) and recovers once allocations succeed again
+        monkeypatch.delenv("KZG_TEST_FAIL_SLOT_ALLOC")
+        eng.srs_generate(secret, n)
+        assert eng.commit_limbs(c).compress() == want
+    finally:
+        eng.close()
+
+
 # ---------------------------------------------------------------- 2^20 (BASELINE config 3, the bench workload)
 
 def test_degree_2_20_commit_and_proof_golden(engines, oracle, golden):

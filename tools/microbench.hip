@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../kzg_poly_commit_exploration_amd/csrc/g1.hip.h"
+#include "../kzg_poly_commit_exploration_amd/csrc/g1_30.hip.h"
 
 using namespace kzg;
 
@@ -260,6 +261,86 @@ __global__ void __launch_bounds__(256) k_fpmul_fips(u32* io, int iters) {
     if (x.l[3] == 0x12345 && y.l[2] == 77) io[48] = 1;
 }
 
+
+// ---- signed radix-2^30 field (field30.hip.h): the same three loops as k_fpmul_fips / k_madd ----------------------
+__global__ void __launch_bounds__(256) k_fqmul(u32* io, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fq x = fq_from_u32x12(io), y = fq_from_u32x12(io + 12);
+    x.d[0] ^= (tid & 0xff);
+    x = fq_mul(x, fq_one());
+    y = fq_mul(y, fq_one());
+    for (int it = 0; it < iters; it++) {
+        x = fq_mul(x, y);
+        y = fq_mul(y, x);
+    }
+    if (tid == 0) {
+        fq_to_u32x12(x, io + 24);
+        fq_to_u32x12(y, io + 36);
+    }
+    if (x.d[3] == 0x12345 && y.d[2] == 77) io[48] = 1;
+}
+__global__ void __launch_bounds__(256) k_fqsqr(u32* io, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fq x = fq_from_u32x12(io);
+    x.d[0] ^= (tid & 0xff);
+    x = fq_mul(x, fq_one());
+    for (int it = 0; it < iters; it++) x = fq_sqr(x);
+    if (tid == 0) fq_to_u32x12(x, io + 24);
+    if (x.d[3] == 0x12345) io[48] = 1;
+}
+__global__ void __launch_bounds__(256) k_fpsqr_fips(u32* io, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Fp x;
+#pragma unroll
+    for (int i = 0; i < 12; i++) x.l[i] = io[i];
+    x.l[0] ^= (tid & 0xff);
+    for (int it = 0; it < iters; it++) x = fe_sqr_fips<FpParams, true>(x);
+    if (tid == 0) {
+        Fp c = fp_canon(x);
+#pragma unroll
+        for (int i = 0; i < 12; i++) io[24 + i] = c.l[i];
+    }
+    if (x.l[3] == 0x12345) io[48] = 1;
+}
+__global__ void __launch_bounds__(256) k_madd30(u32* io, int iters) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    Affine30 p;
+    p.x = fq_mul(fq_from_u32x12(io), fq_one());
+    p.y = fq_mul(fq_from_u32x12(io + 12), fq_one());
+    XYZZ30 acc = xyzz30_inf();
+    xyzz30_madd(acc, p, false);
+    xyzz30_madd(acc, p, false);  // 2P through the doubling branch
+    xyzz30_dbl_inplace(acc);     // 4P
+    for (int it = 0; it < iters; it++) xyzz30_madd(acc, p, (it + tid) & 1);
+    if (tid == 0) {
+        fq_to_u32x12(acc.X, io + 24);
+        fq_to_u32x12(acc.Y, io + 36);
+        fq_to_u32x12(acc.ZZ, io + 48);
+        fq_to_u32x12(acc.ZZZ, io + 60);
+    }
+    if (acc.X.d[3] == 0x12345 && acc.Y.d[2] == 77) io[80] = 1;
+}
+// instruction mix of an fp64-FMA multiplier (Emmart et al.: 52-bit limbs, 8 limbs for 381 bits): per limb product
+// two v_fma_f64 (high and low half), one v_add_f64 (the correction term) and two 64-bit integer adds; 128 limb
+// products per Montgomery product.  NOT a multiplier -- the dependency shape and the instruction counts only.
+__global__ void __launch_bounds__(256) k_dpf_mix(u64* out, int iters) {
+    double a = 1.0 + threadIdx.x * 1e-9, b = 0.999999 + blockIdx.x * 1e-12;
+    const double c1 = 20282409603651670423947251286016.0, c2 = c1 + 4503599627370496.0;  // 2^104, 2^104 + 2^52
+    u64 acc[4] = {1, 2, 3, 4};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int q = 0; q < 128; q++) {
+            double hi = __fma_rn(a, b, c1);
+            double sub = c2 - hi;
+            double lo = __fma_rn(a, b, sub);
+            acc[q & 3] += (u64)__double_as_longlong(hi);
+            acc[(q + 1) & 3] += (u64)__double_as_longlong(lo);
+            a = lo * 1e-30 + a;  // keep the chain data dependent (one more fma; counted in the note)
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc[0] ^ acc[1] ^ acc[2] ^ acc[3];
+}
+
 __global__ void __launch_bounds__(256) k_frmul(u32* io, int iters) {
     int tid = blockIdx.x * blockDim.x + threadIdx.x;
     Fr x, y;
@@ -495,7 +576,100 @@ static int run_carry() {
     return 0;
 }
 
+
+static bool canon_eq(const u32* a_lazy, const u32* b) {
+    // a_lazy in [0, 2p) -> canonical, compare with b (canonical)
+    static const u32 P[12] = {0xffffaaabu, 0xb9feffffu, 0xb153ffffu, 0x1eabfffeu, 0xf6b0f624u, 0x6730d2a0u,
+                              0xf38512bfu, 0x64774b84u, 0x434bacd7u, 0x4b1ba7b6u, 0x397fe69au, 0x1a0111eau};
+    u32 d[12];
+    long long br = 0;
+    for (int i = 0; i < 12; i++) {
+        long long v = (long long)a_lazy[i] - P[i] - br;
+        d[i] = (u32)v;
+        br = v < 0 ? 1 : 0;
+    }
+    const u32* a = br ? a_lazy : d;
+    return memcmp(a, b, 48) == 0;
+}
+
+// Fp multipliers side by side: 12 x u32 FIPS (shipped in round 1), signed radix-2^30 (13 digits), fp64 instruction mix
+static int run_field30() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    int cus = prop.multiProcessorCount;
+    const u32 GX[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
+                        0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
+    const u32 GY[12] = {0x0ce72271u, 0xbaac93d5u, 0x7918fd8eu, 0x8c22631au, 0x570725ceu, 0xdd595f13u,
+                        0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
+    u32 h[128], h2[128];
+    u32* dio;
+    u64* out;
+    CHECK(hipMalloc(&dio, sizeof h));
+    CHECK(hipMalloc(&out, sizeof(u64) * 256 * 8 * 1024));
+    auto reset = [&] {
+        memset(h, 0, sizeof h);
+        memcpy(h, GX, 48);
+        memcpy(h + 12, GY, 48);
+        CHECK(hipMemcpy(dio, h, sizeof h, hipMemcpyHostToDevice));
+    };
+    // correctness first: the same short loops through both representations
+    reset();
+    hipLaunchKernelGGL(k_fpmul_fips, dim3(1), dim3(64), 0, 0, dio, 3);
+    CHECK(hipMemcpy(h, dio, sizeof h, hipMemcpyDeviceToHost));
+    reset();
+    hipLaunchKernelGGL(k_fqmul, dim3(1), dim3(64), 0, 0, dio, 3);
+    CHECK(hipMemcpy(h2, dio, sizeof h2, hipMemcpyDeviceToHost));
+    bool ok_mul = canon_eq(h + 24, h2 + 24) && canon_eq(h + 36, h2 + 36);
+    reset();
+    hipLaunchKernelGGL(k_fpsqr_fips, dim3(1), dim3(64), 0, 0, dio, 5);
+    CHECK(hipMemcpy(h, dio, sizeof h, hipMemcpyDeviceToHost));
+    reset();
+    hipLaunchKernelGGL(k_fqsqr, dim3(1), dim3(64), 0, 0, dio, 5);
+    CHECK(hipMemcpy(h2, dio, sizeof h2, hipMemcpyDeviceToHost));
+    bool ok_sqr = canon_eq(h + 24, h2 + 24);
+    reset();
+    hipLaunchKernelGGL(k_madd, dim3(1), dim3(64), 0, 0, dio, 7);
+    CHECK(hipMemcpy(h, dio, sizeof h, hipMemcpyDeviceToHost));
+    reset();
+    hipLaunchKernelGGL(k_madd30, dim3(1), dim3(64), 0, 0, dio, 7);
+    CHECK(hipMemcpy(h2, dio, sizeof h2, hipMemcpyDeviceToHost));
+    bool ok_madd = canon_eq(h + 24, h2 + 24) && canon_eq(h + 36, h2 + 36) && canon_eq(h + 48, h2 + 48) && canon_eq(h + 60, h2 + 60);
+    printf("{\"probe\": \"field30_vs_fips\", \"mul_equal\": %s, \"sqr_equal\": %s, \"madd_equal\": %s}\n", ok_mul ? "true" : "false",
+           ok_sqr ? "true" : "false", ok_madd ? "true" : "false");
+    for (int wps = 1; wps <= 4; wps++) {
+        int grid = cus * wps;
+        const int fit = 200, block = 256;
+        double nmul = (double)grid * block * fit * 2;
+        reset();
+        double ms = time_kernel(k_fpmul_fips, grid, block, 3, dio, fit);
+        printf("{\"bench\": \"fp_mul_fips\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gmul_s\": %.2f}\n", wps, ms, nmul / ms / 1e6);
+        reset();
+        ms = time_kernel(k_fqmul, grid, block, 3, dio, fit);
+        printf("{\"bench\": \"fp_mul_signed30\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gmul_s\": %.2f}\n", wps, ms, nmul / ms / 1e6);
+        reset();
+        ms = time_kernel(k_fpsqr_fips, grid, block, 3, dio, 2 * fit);
+        printf("{\"bench\": \"fp_sqr_fips\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gsqr_s\": %.2f}\n", wps, ms, nmul / ms / 1e6);
+        reset();
+        ms = time_kernel(k_fqsqr, grid, block, 3, dio, 2 * fit);
+        printf("{\"bench\": \"fp_sqr_signed30\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gsqr_s\": %.2f}\n", wps, ms, nmul / ms / 1e6);
+        ms = time_kernel(k_dpf_mix, grid, block, 3, out, fit);
+        printf("{\"bench\": \"fp_mul_fp64_instruction_mix\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gmul_s_equivalent\": %.2f, \"note\": \"2 v_fma_f64 + v_add_f64 + 2 u64 adds (+1 chaining fma) x 128 limb products; not a multiplier\"}\n",
+               wps, ms, (double)grid * block * fit / ms / 1e6);
+        const int mit = 64;
+        double nadd = (double)grid * block * mit;
+        reset();
+        ms = time_kernel(k_madd, grid, block, 3, dio, mit);
+        printf("{\"bench\": \"xyzz_madd_fips\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gadd_s\": %.3f}\n", wps, ms, nadd / ms / 1e6);
+        reset();
+        ms = time_kernel(k_madd30, grid, block, 3, dio, mit);
+        printf("{\"bench\": \"xyzz_madd_signed30\", \"waves_per_simd\": %d, \"ms\": %.4f, \"Gadd_s\": %.3f}\n", wps, ms, nadd / ms / 1e6);
+        fflush(stdout);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "field30")) return run_field30();
     if (argc > 1 && !strcmp(argv[1], "carrydbg")) return run_carry_debug();
     if (argc > 1 && !strcmp(argv[1], "carry")) return run_carry();
     if (argc > 1 && !strcmp(argv[1], "mix")) return run_mix_all();
