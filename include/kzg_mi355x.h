@@ -55,6 +55,22 @@ typedef enum kzg_status {
  * No reference analogue: the reference is stateless and receives the SRS slice on every call
  * (src/polynomial.rs:200); the context exists to keep the SRS resident in HBM. */
 int kzg_ctx_create(int device, kzg_ctx** out);
+/* One context over `ndev` HIP devices of this node (the signature SURVEY.md section 8(b) sketched).  The SRS is
+ * split by point range: devices[g] keeps points [g * ceil(n/ndev), ...) resident with their window tables
+ * (kzg_srs_load_g1 / kzg_srs_generate_g1 on the context do the split).  kzg_commit, kzg_commit_le_bytes and kzg_open
+ * then shard transparently -- one partial MSM per device driven by its own host thread; a range-sharded opening
+ * evaluates the slices, runs the ndev-step carry recurrence on the host and opens every slice extended by its carry
+ * (replaces the same bodies, reference src/polynomial.rs:200-215 and 260-269) -- and the 144-byte partial sums are
+ * exchanged with ncclAllGather (librccl, one communicator per device, single process) and added with kzg_g1_sum:
+ * RCCL has no reduction operator for curve points, so "reduce" = all-gather + K-1 complete additions.
+ * A device may be listed more than once (virtual slices: how a one-GPU box rehearses the path); such a context
+ * gathers on the host, since a communicator needs distinct devices.  ndev == 1 behaves like kzg_ctx_create.
+ * kzg_evaluate / kzg_quotient run on devices[0].  The asynchronous and device-pointer entry points (submit / wait /
+ * batch / kzg_dev_*) belong to one device and return KZG_ERR_INVALID_ARG on a multi-device context. */
+int kzg_ctx_create_multi(const int* devices, int ndev, kzg_ctx** out);
+/* devices of the context (1 for kzg_ctx_create) and how many partial-sum exchanges went through RCCL so far */
+int kzg_num_devices(const kzg_ctx* ctx);
+uint64_t kzg_rccl_exchanges(const kzg_ctx* ctx);
 void kzg_ctx_destroy(kzg_ctx* ctx);
 const char* kzg_strerror(int status);
 /* text of the last KZG_ERR_HIP on this context (valid until the next call on it) */

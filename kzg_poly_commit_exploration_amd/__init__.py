@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "kzg_ctx_create", "kzg_ctx_destroy", "kzg_strerror", "kzg_last_error",
     "kzg_srs_load_g1", "kzg_srs_generate_g1", "kzg_srs_read_g1", "kzg_srs_len",
     "kzg_commit", "kzg_commit_le_bytes", "kzg_open", "kzg_quotient", "kzg_evaluate",
-    "kzg_num_slots", "kzg_commit_submit", "kzg_open_submit", "kzg_wait",
+    "kzg_ctx_create_multi", "kzg_num_devices", "kzg_rccl_exchanges", "kzg_num_slots", "kzg_commit_submit", "kzg_open_submit", "kzg_wait",
     "kzg_set_max_batch", "kzg_max_batch", "kzg_commit_batch_submit", "kzg_wait_batch",
     "kzg_open_batch_submit", "kzg_wait_open_batch", "kzg_g1_uncompress",
     "kzg_dev_alloc", "kzg_dev_free", "kzg_dev_upload", "kzg_dev_download",
@@ -84,6 +84,9 @@ def load_library():
     vp, sz, u8p, i = C.c_void_p, C.c_size_t, C.c_char_p, C.c_int
     sig = {
         "kzg_ctx_create": (i, [i, C.POINTER(vp)]),
+        "kzg_ctx_create_multi": (i, [vp, i, C.POINTER(vp)]),
+        "kzg_num_devices": (i, [vp]),
+        "kzg_rccl_exchanges": (C.c_uint64, [vp]),
         "kzg_ctx_destroy": (None, [vp]),
         "kzg_strerror": (C.c_char_p, [i]),
         "kzg_last_error": (C.c_char_p, [vp]),
@@ -281,12 +284,25 @@ def _check(rc, ctx=None):
 # Engine: one context = one GPU with a resident SRS (no reference analogue; see kzg_mi355x.h).
 # ---------------------------------------------------------------------------------------------
 class Engine:
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """device: one HIP device.  devices=[d0, d1, ...]: one context over several devices (kzg_ctx_create_multi):
+        the SRS is split by point range and commit / open shard transparently; a device may repeat (virtual slices)."""
         self._lib = load_library()
         h = C.c_void_p()
-        _check(self._lib.kzg_ctx_create(int(device), C.byref(h)))
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            _check(self._lib.kzg_ctx_create_multi(arr, len(devices), C.byref(h)))
+            device = int(devices[0])
+        else:
+            _check(self._lib.kzg_ctx_create(int(device), C.byref(h)))
         self._h = h
         self.device = device
+
+    def num_devices(self):
+        return int(self._lib.kzg_num_devices(self._h))
+
+    def rccl_exchanges(self):
+        return int(self._lib.kzg_rccl_exchanges(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -90,6 +90,9 @@ struct Slot {
 __global__ void k_reduce_gate(uint32_t* sink);  // defined below
 
 struct kzg_ctx {
+    // a multi-device context (kzg_ctx_create_multi) only carries this pointer: its calls are sharded over the
+    // single-device contexts inside (multi.hip)
+    kzg::MultiState* multi = nullptr;
     int device = 0;
     std::mutex mu;
     std::string last_error;
@@ -283,6 +286,8 @@ int build_tables(kzg_ctx* ctx, hipStream_t st, void* d_xyzz_tmp, void* d_prefix)
         char* next = (char*)ctx->d_table + (size_t)j * n * kAffineBytes;
         launch_table_window(st, prev, (uint32_t)n, ctx->cfg.level_bits, d_xyzz_tmp, d_prefix, next);
     }
+    // every level is complete: rewrite the records into the accumulation kernel's native field representation
+    launch_table_to_fq(st, ctx->d_table, (uint64_t)ctx->cfg.W * n);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return KZG_OK;
@@ -448,6 +453,15 @@ __global__ void k_tail_nonzero(const uint32_t* __restrict__ c, uint64_t from, ui
     if (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) atomicOr(flag, 1u);
 }
 
+// asynchronous / device-pointer entry points belong to ONE device: refused on a multi-device context
+#define KZG_SINGLE_DEVICE_ONLY(ctx)                                                                        \
+    do {                                                                                                     \
+        if ((ctx) && (ctx)->multi) {                                                                         \
+            (ctx)->last_error = "this entry point takes a single-device context (kzg_ctx_create)";           \
+            return KZG_ERR_INVALID_ARG;                                                                      \
+        }                                                                                                    \
+    } while (0)
+
 extern "C" {
 
 const char* kzg_strerror(int status) {
@@ -467,7 +481,28 @@ const char* kzg_strerror(int status) {
     }
 }
 
-const char* kzg_last_error(const kzg_ctx* ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+const char* kzg_last_error(const kzg_ctx* ctx) {
+    if (!ctx) return "";
+    if (ctx->multi && ctx->last_error.empty()) return multi_last_error(ctx->multi);
+    return ctx->last_error.c_str();
+}
+
+int kzg_ctx_create_multi(const int* devices, int ndev, kzg_ctx** out) {
+    if (!out) return KZG_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!devices || ndev <= 0) return KZG_ERR_INVALID_ARG;
+    kzg::MultiState* m = nullptr;
+    std::string err;
+    int rc = multi_create(devices, ndev, &m, err);
+    if (rc != KZG_OK) return rc;
+    kzg_ctx* ctx = new kzg_ctx();
+    ctx->multi = m;
+    ctx->device = devices[0];
+    *out = ctx;
+    return KZG_OK;
+}
+int kzg_num_devices(const kzg_ctx* ctx) { return !ctx ? 0 : (ctx->multi ? multi_num_devices(ctx->multi) : 1); }
+uint64_t kzg_rccl_exchanges(const kzg_ctx* ctx) { return (ctx && ctx->multi) ? multi_rccl_exchanges(ctx->multi) : 0; }
 
 int kzg_ctx_create(int device, kzg_ctx** out) {
     if (!out) return KZG_ERR_INVALID_ARG;
@@ -495,6 +530,11 @@ int kzg_ctx_create(int device, kzg_ctx** out) {
 
 void kzg_ctx_destroy(kzg_ctx* ctx) {
     if (!ctx) return;
+    if (ctx->multi) {
+        multi_destroy(ctx->multi);
+        delete ctx;
+        return;
+    }
     hipSetDevice(ctx->device);
     for (auto& s : ctx->slots) {
         if (s.stream) hipStreamSynchronize(s.stream);
@@ -516,10 +556,12 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
     delete ctx;
 }
 
-size_t kzg_srs_len(const kzg_ctx* ctx) { return ctx ? ctx->n : 0; }
+size_t kzg_srs_len(const kzg_ctx* ctx) { return !ctx ? 0 : (ctx->multi ? multi_srs_len(ctx->multi) : ctx->n); }
 int kzg_num_slots(const kzg_ctx*) { return kNumSlots; }
 
 int kzg_msm_config(const kzg_ctx* ctx, int* digit_bits, int* table_levels, size_t* num_buckets, int* recoding) {
+    if (ctx && ctx->multi)  // the first slice's configuration (all slices have the same length up to one point)
+        return kzg_msm_config(multi_kid(ctx->multi, 0), digit_bits, table_levels, num_buckets, recoding);
     if (!ctx || !ctx->n) return KZG_ERR_NO_SRS;
     if (digit_bits) *digit_bits = (int)ctx->cfg.c;
     if (table_levels) *table_levels = (int)ctx->cfg.W;
@@ -530,6 +572,11 @@ int kzg_msm_config(const kzg_ctx* ctx, int* digit_bits, int* table_levels, size_
 
 int kzg_srs_load_g1(kzg_ctx* ctx, const void* first_g1, size_t stride, size_t n) {
     if (!ctx || !first_g1 || stride < 144) return KZG_ERR_INVALID_ARG;
+    if (ctx->multi) {
+        std::lock_guard<std::mutex> lkm(ctx->mu);
+        ctx->last_error.clear();
+        return n ? multi_srs_load(ctx->multi, first_g1, stride, n) : KZG_ERR_INVALID_ARG;
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = srs_prepare(ctx, n);
@@ -556,6 +603,11 @@ int kzg_srs_load_g1(kzg_ctx* ctx, const void* first_g1, size_t stride, size_t n)
 
 int kzg_srs_generate_g1(kzg_ctx* ctx, const uint8_t secret_be[32], uint64_t first, size_t n) {
     if (!ctx || !secret_be) return KZG_ERR_INVALID_ARG;
+    if (ctx->multi) {
+        std::lock_guard<std::mutex> lkm(ctx->mu);
+        ctx->last_error.clear();
+        return n ? multi_srs_generate(ctx->multi, secret_be, first, n) : KZG_ERR_INVALID_ARG;
+    }
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = srs_prepare(ctx, n);
@@ -586,6 +638,7 @@ int kzg_srs_generate_g1(kzg_ctx* ctx, const uint8_t secret_be[32], uint64_t firs
 int kzg_srs_read_g1(kzg_ctx* ctx, size_t index, size_t count, uint64_t* out_p1) {
     if (!ctx || !out_p1) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->multi) return multi_srs_len(ctx->multi) ? multi_srs_read(ctx->multi, index, count, out_p1) : KZG_ERR_NO_SRS;
     if (!ctx->n) return KZG_ERR_NO_SRS;
     if (index > ctx->n || count > ctx->n - index) return KZG_ERR_INVALID_ARG;
     if (!count) return KZG_OK;
@@ -636,6 +689,7 @@ static int submit_commit_locked(kzg_ctx* ctx, int slot, const uint32_t* d_scalar
 }
 
 int kzg_commit_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || (!d_coeffs && n)) return KZG_ERR_INVALID_ARG;
     if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -689,6 +743,7 @@ static int submit_open_locked(kzg_ctx* ctx, int slot, const uint32_t* d_coeffs, 
 }
 
 int kzg_open_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, const uint64_t z[4], const uint64_t y[4]) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || !z || !y || (!d_coeffs && n)) return KZG_ERR_INVALID_ARG;
     if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -756,6 +811,7 @@ static int wait_locked(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
 }
 
 int kzg_set_max_batch(kzg_ctx* ctx, size_t max_batch) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || max_batch == 0) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -782,6 +838,7 @@ size_t kzg_max_batch(const kzg_ctx* ctx) { return ctx ? ctx->max_batch : 0; }
 
 int kzg_commit_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch,
                             size_t stride_coeffs) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || !d_coeffs || n == 0 || batch == 0 || stride_coeffs < n || n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
@@ -806,6 +863,7 @@ int kzg_commit_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t
 }
 
 int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || !out_p1s) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
@@ -844,6 +902,7 @@ int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
 // ONE batched MSM over the `batch` quotients.
 int kzg_open_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch, size_t stride_coeffs,
                           const uint64_t* zs, const uint64_t* ys) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || !d_coeffs || !zs || !ys || n < 2 || batch == 0 || stride_coeffs < n || n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
@@ -893,6 +952,7 @@ int kzg_open_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n
 }
 
 int kzg_wait_open_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, int* statuses, size_t batch) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || !out_p1s || !statuses) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
@@ -932,6 +992,7 @@ int kzg_wait_open_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, int* statuses
 }
 
 int kzg_wait(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || !out_p1) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     return wait_locked(ctx, slot, out_p1);
@@ -949,6 +1010,10 @@ static int commit_host(kzg_ctx* ctx, const void* scalars, int is_mont, size_t n,
     if (!ctx || !out_p1 || (!scalars && n)) return KZG_ERR_INVALID_ARG;
     if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->multi) {
+        ctx->last_error.clear();
+        return multi_commit(ctx->multi, scalars, is_mont, n, out_p1);
+    }
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
     int slot = find_idle_slot(ctx);
     if (slot < 0) return KZG_ERR_BUSY;
@@ -976,6 +1041,10 @@ int kzg_open(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4]
     if (!ctx || !out_p1 || !z || !y || (!coeffs && n)) return KZG_ERR_INVALID_ARG;
     if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->multi) {
+        ctx->last_error.clear();
+        return multi_open(ctx->multi, coeffs, n, z, y, out_p1);
+    }
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
     int slot = find_idle_slot(ctx);
     if (slot < 0) return KZG_ERR_BUSY;
@@ -993,6 +1062,7 @@ int kzg_quotient(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t 
                  uint64_t* out_q, size_t* out_qn) {
     if (!ctx || !z || !y || !out_qn || (!coeffs && n) || (!out_q && n > 1)) return KZG_ERR_INVALID_ARG;
     if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
+    if (ctx->multi) return kzg_quotient(multi_kid(ctx->multi, 0), coeffs, n, z, y, out_q, out_qn);  // needs no SRS
     std::lock_guard<std::mutex> lk(ctx->mu);
     *out_qn = 0;
     int slot = find_idle_slot(ctx);
@@ -1030,6 +1100,7 @@ int kzg_quotient(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t 
 int kzg_evaluate(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4], uint64_t out_y[4]) {
     if (!ctx || !z || !out_y || (!coeffs && n)) return KZG_ERR_INVALID_ARG;
     if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
+    if (ctx->multi) return kzg_evaluate(multi_kid(ctx->multi, 0), coeffs, n, z, out_y);  // needs no SRS
     std::lock_guard<std::mutex> lk(ctx->mu);
     std::memset(out_y, 0, 32);
     if (n == 0) return KZG_OK;
@@ -1057,6 +1128,7 @@ int kzg_evaluate(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t 
 // ---- raw device memory -----------------------------------------------------------------------
 
 int kzg_dev_alloc(kzg_ctx* ctx, size_t bytes, void** out) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || !out) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1064,6 +1136,7 @@ int kzg_dev_alloc(kzg_ctx* ctx, size_t bytes, void** out) {
     return KZG_OK;
 }
 int kzg_dev_free(kzg_ctx* ctx, void* p) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1071,6 +1144,7 @@ int kzg_dev_free(kzg_ctx* ctx, void* p) {
     return KZG_OK;
 }
 int kzg_dev_upload(kzg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || (!dst && bytes) || (!src && bytes)) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1078,6 +1152,7 @@ int kzg_dev_upload(kzg_ctx* ctx, void* dst, const void* src, size_t bytes) {
     return KZG_OK;
 }
 int kzg_dev_download(kzg_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || (!dst && bytes) || (!src && bytes)) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1154,12 +1229,14 @@ int kzg_verify_proof_batch(const uint64_t* commitments_p1, const uint64_t* proof
 // ---- measurement ---------------------------------------------------------------------------------
 
 int kzg_set_timing(kzg_ctx* ctx, int enabled) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->timing = enabled != 0;
     return KZG_OK;
 }
 int kzg_get_times(kzg_ctx* ctx, int slot, kzg_kernel_times* out) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || !out || slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
     *out = ctx->slots[slot].times;

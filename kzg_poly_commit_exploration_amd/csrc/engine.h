@@ -14,9 +14,11 @@ namespace kzg {
 // level-major, T[j * n + i] = 2^(level_bits*j) * SRS[i]  (j < W), so level 0 is the SRS itself.
 constexpr size_t kAffineBytes = 128;
 constexpr size_t kAffineU4 = kAffineBytes / 16;  // record stride in uint4 units
-// One XYZZ accumulator in HBM: X, Y, ZZ, ZZZ, 4 x 12 u32 = 192 bytes.
-constexpr size_t kXyzzBytes = 192;
-constexpr size_t kXyzzWords64 = 24;
+// One XYZZ accumulator in HBM: X, Y, ZZ, ZZZ as four groups of 13 signed radix-2^30 digits (field30.hip.h,
+// Montgomery R' = 2^390, lazily reduced), each group padded to 16 words: 256 bytes, all zero = infinity.
+constexpr size_t kXyzzBytes = 256;
+constexpr size_t kXyzzU4 = kXyzzBytes / 16;      // record stride in uint4 units
+constexpr size_t kXyzzWords64 = kXyzzBytes / 8;  // record stride in u64 units (host side)
 
 // Two scalar recodings share every kernel after the digit loop:
 //   kRecodeWindows  aligned signed windows of c bits: W = ceil(255/c) digits per scalar, one table level per
@@ -105,8 +107,31 @@ void launch_table_window(hipStream_t s, const void* d_prev_affine, uint32_t n, u
 void launch_srs_generate(hipStream_t s, const uint32_t* secret_raw8 /* 256-bit LE integer */, uint64_t first, uint32_t n,
                          void* d_gtable, void* d_xyzz_tmp, void* d_prefix_tmp, void* d_affine_out);
 size_t srs_gtable_bytes();
-// affine table entries -> blst_p1 (Z = Montgomery one / all zero for infinity)
+// ---- msm_accum.hip (table format) ---------------------------------------------------------
+// rewrites `records` finished table records in place from the builder's 12 x u32 form into the accumulation kernel's
+// native form (13 signed radix-2^30 digits per coordinate, x in words 0..12, y in words 16..28 of the 128-B record)
+void launch_table_to_fq(hipStream_t s, void* d_table, uint64_t records);
+// native table entries -> blst_p1 (Z = Montgomery one / all zero for infinity)
 void launch_affine_to_p1(hipStream_t s, const void* d_affine, uint32_t n, void* d_p1_out);
+
+// ---- multi.hip: a context spanning several devices (SRS-range slices, RCCL exchange of the partials) ------------
+}  // namespace kzg
+#include <string>
+struct kzg_ctx;
+namespace kzg {
+struct MultiState;
+int multi_create(const int* devices, int ndev, MultiState** out, std::string& err);
+void multi_destroy(MultiState* m);
+size_t multi_srs_len(const MultiState* m);
+int multi_num_devices(const MultiState* m);
+uint64_t multi_rccl_exchanges(const MultiState* m);
+kzg_ctx* multi_kid(MultiState* m, int g);
+const char* multi_last_error(const MultiState* m);
+int multi_srs_generate(MultiState* m, const uint8_t secret_be[32], uint64_t first, size_t n);
+int multi_srs_load(MultiState* m, const void* first_g1, size_t stride, size_t n);
+int multi_srs_read(MultiState* m, size_t index, size_t count, uint64_t* out_p1);
+int multi_commit(MultiState* m, const void* scalars, int is_mont, size_t n, uint64_t out_p1[18]);
+int multi_open(MultiState* m, const uint64_t* coeffs, size_t n, const uint64_t z[4], const uint64_t y[4], uint64_t out_p1[18]);
 
 // ---- poly_kernels.hip -------------------------------------------------------------------
 struct PolyScratch {

@@ -52,6 +52,14 @@ KZG_HD int32_t fq_sext30(uint32_t v) { return (int32_t)(v << 2) >> 2; }  // low 
 // (acc - balanced low digit) >> 30  ==  (acc + 2^29) >> 30: one 64-bit add and one 64-bit shift
 KZG_HD int64_t fq_round_shift(int64_t acc) { return (acc + (int64_t)(1 << (kQBits - 1))) >> kQBits; }
 
+// KZG_F30_SERIAL_COLUMNS: keep the columns of a product in program order (one live accumulator) instead of letting
+// the compiler run a dozen of them side by side -- fewer VGPRs, less instruction-level parallelism
+#if defined(KZG_F30_SERIAL_COLUMNS) && defined(__HIP_DEVICE_COMPILE__)
+#define KZG_F30_FENCE(acc) asm volatile("" : "+v"(acc))
+#else
+#define KZG_F30_FENCE(acc) ((void)0)
+#endif
+
 KZG_HD Fq fq_zero() {
     Fq r;
 #pragma unroll
@@ -144,6 +152,7 @@ KZG_HD Fq fq_mul(const Fq& a, const Fq& b) {
         m[k] = fq_sext30((uint32_t)acc * kQN0);
         acc += (int64_t)m[k] * fq_pd(0);  // low 30 bits are now zero
         acc >>= kQBits;
+        KZG_F30_FENCE(acc);
     }
 #pragma unroll
     for (int k = kQ; k < 2 * kQ - 1; k++) {
@@ -153,6 +162,7 @@ KZG_HD Fq fq_mul(const Fq& a, const Fq& b) {
         for (int j = k - kQ + 1; j < kQ; j++) acc += (int64_t)m[j] * fq_pd(k - j);
         r.d[k - kQ] = fq_sext30((uint32_t)acc);
         acc = fq_round_shift(acc);
+        KZG_F30_FENCE(acc);
     }
     r.d[kQ - 1] = (int32_t)acc;
     return r;
@@ -175,6 +185,7 @@ KZG_HD Fq fq_sqr(const Fq& a) {
         m[k] = fq_sext30((uint32_t)acc * kQN0);
         acc += (int64_t)m[k] * fq_pd(0);
         acc >>= kQBits;
+        KZG_F30_FENCE(acc);
     }
 #pragma unroll
     for (int k = kQ; k < 2 * kQ - 1; k++) {
@@ -185,6 +196,7 @@ KZG_HD Fq fq_sqr(const Fq& a) {
         for (int j = k - kQ + 1; j < kQ; j++) acc += (int64_t)m[j] * fq_pd(k - j);
         r.d[k - kQ] = fq_sext30((uint32_t)acc);
         acc = fq_round_shift(acc);
+        KZG_F30_FENCE(acc);
     }
     r.d[kQ - 1] = (int32_t)acc;
     return r;
@@ -247,6 +259,26 @@ KZG_HD Fq fq_from_u32x12(const uint32_t* s) {
     }
     r.d[kQ - 1] = (int32_t)u[kQ - 1] + c;
     return r;
+}
+
+KZG_HD Fq fq_one() {  // 2^390 mod p, balanced digits (tools/gen_field30_constants.py)
+    Fq c;
+    constexpr int32_t V[13] = {
+#include "field30_one.inc"
+    };
+#pragma unroll
+    for (int i = 0; i < kQ; i++) c.d[i] = V[i];
+    return c;
+}
+
+KZG_HD Fq fq_const_2_1170() {  // 2^1170 mod p: v^-1 (as an integer) times this, as a Montgomery product, is the inverse's Montgomery form
+    Fq c;
+    constexpr int32_t V[13] = {
+#include "field30_c1170.inc"
+    };
+#pragma unroll
+    for (int i = 0; i < kQ; i++) c.d[i] = V[i];
+    return c;
 }
 
 // Montgomery R' -> R: multiply by 2^384 (as a Montgomery factor: the constant 2^384 mod p in digits), then make

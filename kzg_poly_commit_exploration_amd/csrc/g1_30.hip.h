@@ -29,16 +29,6 @@ struct XYZZ30 {
     Fq X, Y, ZZ, ZZZ;
 };
 
-KZG_HD Fq fq_one() {  // 2^390 mod p, balanced digits (tools/gen_field30_constants.py)
-    Fq c;
-    constexpr int32_t V[13] = {
-#include "field30_one.inc"
-    };
-#pragma unroll
-    for (int i = 0; i < kQ; i++) c.d[i] = V[i];
-    return c;
-}
-
 KZG_HD bool fq_all_zero(const Fq& a) {
     int32_t o = 0;
 #pragma unroll
@@ -56,14 +46,8 @@ KZG_HD XYZZ30 xyzz30_inf() {
 }
 KZG_HD bool xyzz30_is_inf(const XYZZ30& a) { return fq_all_zero(a.ZZ); }  // infinity is only ever written as exact zeros
 
-// 2 * a (dbl-2008-s-1).  Rare path of the additions (equal operands) and the table construction.
-#ifdef __HIPCC__
-__device__ __noinline__
-#else
-inline
-#endif
-    void
-    xyzz30_dbl_inplace(XYZZ30& a) {
+// 2 * a (dbl-2008-s-1)
+KZG_HD void xyzz30_dbl_body(XYZZ30& a) {
     if (xyzz30_is_inf(a) || fq_is_zero(a.Y)) {
         a = xyzz30_inf();
         return;
@@ -81,27 +65,48 @@ inline
     a.X = X3;
     a.Y = Y3;
 }
+// the same as a real call: the rare equal-operands branch of the accumulation kernel must not set the register
+// budget of its hot loop (KZG_G1_30_INLINE_DBL: kernels that prefer no private memory inline it instead)
+// The accumulator itself must never have its address taken (it would live in private memory for the whole kernel):
+// the call works on a copy.
+#if defined(__HIPCC__) && !defined(KZG_G1_30_INLINE_DBL)
+static __device__ __noinline__ void xyzz30_dbl_call(XYZZ30* io) { xyzz30_dbl_body(*io); }
+__device__ __forceinline__ void xyzz30_dbl_inplace(XYZZ30& a) {
+    XYZZ30 tmp = a;
+    xyzz30_dbl_call(&tmp);
+    a = tmp;
+}
+#else
+KZG_HD void xyzz30_dbl_inplace(XYZZ30& a) { xyzz30_dbl_body(a); }
+#endif
 
-// acc += p (affine), p negated when `neg`; complete.
-KZG_HD void xyzz30_madd(XYZZ30& acc, const Affine30& p_in, bool neg) {
-    if (fq_all_zero(p_in.x) && fq_all_zero(p_in.y)) return;
+// acc += p (affine), p negated when `neg`; complete.  Two halves so that a caller can reuse the registers of the
+// point between them (the accumulation kernel issues the gather of its next point there):
+//   xyzz30_madd_head  consumes the point: returns false when the addition is already complete (a trivial or
+//                     exceptional case), true with P = U2 - X1 and R = S2 - Y1 otherwise;
+//   xyzz30_madd_tail  the remaining 6M + 2S on (acc, P, R).
+KZG_HD bool xyzz30_madd_head(XYZZ30& acc, const Affine30& p_in, bool neg, Fq& P, Fq& R) {
+    if (fq_all_zero(p_in.x) && fq_all_zero(p_in.y)) return false;
     const Fq py = fq_cneg(p_in.y, neg);
     if (xyzz30_is_inf(acc)) {
         acc.X = p_in.x;
         acc.Y = py;
         acc.ZZ = fq_one();
         acc.ZZZ = fq_one();
-        return;
+        return false;
     }
-    const Fq P = fq_norm(fq_sub_raw(fq_mul(p_in.x, acc.ZZ), acc.X));  // U2 - X1
+    P = fq_norm(fq_sub_raw(fq_mul(p_in.x, acc.ZZ), acc.X));  // U2 - X1
     KZG_SB30();
-    const Fq R = fq_norm(fq_sub_raw(fq_mul(py, acc.ZZZ), acc.Y));     // S2 - Y1
+    R = fq_norm(fq_sub_raw(fq_mul(py, acc.ZZZ), acc.Y));     // S2 - Y1
     KZG_SB30();
     if (fq_is_zero(P)) {
         if (fq_is_zero(R)) xyzz30_dbl_inplace(acc);  // acc == p as group elements
         else acc = xyzz30_inf();
-        return;
+        return false;
     }
+    return true;
+}
+KZG_HD void xyzz30_madd_tail(XYZZ30& acc, const Fq& P, const Fq& R) {
     const Fq PP = fq_sqr(P);
     KZG_SB30();
     acc.ZZ = fq_mul(acc.ZZ, PP);
@@ -120,5 +125,93 @@ KZG_HD void xyzz30_madd(XYZZ30& acc, const Affine30& p_in, bool neg) {
     KZG_SB30();
     acc.X = X3;
 }
+KZG_HD void xyzz30_madd(XYZZ30& acc, const Affine30& p_in, bool neg) {
+    Fq P, R;
+    if (xyzz30_madd_head(acc, p_in, neg, P, R)) xyzz30_madd_tail(acc, P, R);
+}
+
+// acc += b (add-2008-s: 12M + 2S), complete
+KZG_HD void xyzz30_add(XYZZ30& acc, const XYZZ30& b) {
+    if (xyzz30_is_inf(b)) return;
+    if (xyzz30_is_inf(acc)) {
+        acc = b;
+        return;
+    }
+    const Fq U1 = fq_mul(acc.X, b.ZZ);
+    KZG_SB30();
+    const Fq P = fq_norm(fq_sub_raw(fq_mul(b.X, acc.ZZ), U1));
+    KZG_SB30();
+    const Fq S1 = fq_mul(acc.Y, b.ZZZ);
+    KZG_SB30();
+    const Fq R = fq_norm(fq_sub_raw(fq_mul(b.Y, acc.ZZZ), S1));
+    KZG_SB30();
+    if (fq_is_zero(P)) {
+        if (fq_is_zero(R)) xyzz30_dbl_inplace(acc);
+        else acc = xyzz30_inf();
+        return;
+    }
+    const Fq PP = fq_sqr(P);
+    KZG_SB30();
+    acc.ZZ = fq_mul(fq_mul(acc.ZZ, b.ZZ), PP);
+    KZG_SB30();
+    const Fq Q = fq_mul(U1, PP);
+    KZG_SB30();
+    const Fq PPP = fq_mul(P, PP);
+    KZG_SB30();
+    acc.ZZZ = fq_mul(fq_mul(acc.ZZZ, b.ZZZ), PPP);
+    KZG_SB30();
+    const Fq YP = fq_mul(S1, PPP);
+    KZG_SB30();
+    const Fq X3 = fq_norm_wide(fq_sub_raw(fq_sub_raw(fq_sqr(R), PPP), fq_add_raw(Q, Q)));
+    KZG_SB30();
+    acc.Y = fq_norm(fq_sub_raw(fq_mul(R, fq_sub_raw(Q, X3)), YP));
+    acc.X = X3;
+}
+
+// The general addition as ONE real call with its operands in private memory: the latency-bound finalisation and
+// reduction kernels (a dozen dependent additions per lane) then keep one register allocation of ~200 VGPRs for the
+// addition and nothing else, instead of several inlined copies whose live ranges the compiler merges into 400+.
+#if defined(__HIPCC__)
+static __device__ __noinline__ void xyzz30_add_call(XYZZ30* acc, const XYZZ30* b) {
+    XYZZ30 a = *acc;
+    const XYZZ30 o = *b;
+    xyzz30_add(a, o);
+    *acc = a;
+}
+#endif
+
+// XYZZ record in HBM (engine.h kXyzzBytes = 256): coordinate c (X, Y, ZZ, ZZZ) in words 16 c .. 16 c + 12
+#ifdef __HIPCC__
+__device__ __forceinline__ Fq load_fq16(const uint4* __restrict__ p) {
+    const uint4 a = p[0], b = p[1], c = p[2];
+    const uint32_t d = reinterpret_cast<const uint32_t*>(p)[12];
+    Fq r;
+    r.d[0] = (int32_t)a.x; r.d[1] = (int32_t)a.y; r.d[2] = (int32_t)a.z; r.d[3] = (int32_t)a.w;
+    r.d[4] = (int32_t)b.x; r.d[5] = (int32_t)b.y; r.d[6] = (int32_t)b.z; r.d[7] = (int32_t)b.w;
+    r.d[8] = (int32_t)c.x; r.d[9] = (int32_t)c.y; r.d[10] = (int32_t)c.z; r.d[11] = (int32_t)c.w;
+    r.d[12] = (int32_t)d;
+    return r;
+}
+__device__ __forceinline__ void store_fq16(uint4* __restrict__ p, const Fq& a) {
+    p[0] = make_uint4((uint32_t)a.d[0], (uint32_t)a.d[1], (uint32_t)a.d[2], (uint32_t)a.d[3]);
+    p[1] = make_uint4((uint32_t)a.d[4], (uint32_t)a.d[5], (uint32_t)a.d[6], (uint32_t)a.d[7]);
+    p[2] = make_uint4((uint32_t)a.d[8], (uint32_t)a.d[9], (uint32_t)a.d[10], (uint32_t)a.d[11]);
+    p[3] = make_uint4((uint32_t)a.d[12], 0u, 0u, 0u);
+}
+__device__ __forceinline__ XYZZ30 load_xyzz30(const uint4* __restrict__ rec) {
+    XYZZ30 a;
+    a.X = load_fq16(rec);
+    a.Y = load_fq16(rec + 4);
+    a.ZZ = load_fq16(rec + 8);
+    a.ZZZ = load_fq16(rec + 12);
+    return a;
+}
+__device__ __forceinline__ void store_xyzz30(uint4* __restrict__ rec, const XYZZ30& a) {
+    store_fq16(rec, a.X);
+    store_fq16(rec + 4, a.Y);
+    store_fq16(rec + 8, a.ZZ);
+    store_fq16(rec + 12, a.ZZZ);
+}
+#endif
 
 }  // namespace kzg

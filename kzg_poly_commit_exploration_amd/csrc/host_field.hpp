@@ -171,17 +171,44 @@ inline P1 p1_normalize(const P1& p) {  // affine with z = R (Montgomery one), or
     r.z = kOne;
     return r;
 }
-// device XYZZ partial sum (X, Y, ZZ, ZZZ as 4 x 6 u64) -> Jacobian with Z = ZZ: X*ZZ, Y*ZZZ, ZZ
+// One coordinate of a device XYZZ record: 13 signed radix-2^30 digits of a lazily reduced integer v = x * 2^390
+// + k p, |v| < 3.5 p (csrc/field30.hip.h)  ->  this file's Montgomery form x * 2^384 mod p.
+// v + 4p is positive and below 2^384; (v + 4p) * 2^378 / 2^384 = v * 2^-6 = x * 2^384.
+inline Fp fp_from_digits30(const int32_t d[13]) {
+    // two's-complement accumulation in seven 64-bit words: big = big * 2^30 + d[i], most significant digit first
+    uint64_t w[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = 12; i >= 0; --i) {
+        for (int k = 6; k > 0; --k) w[k] = (w[k] << 30) | (w[k - 1] >> 34);
+        w[0] <<= 30;
+        const int64_t add = d[i];
+        const uint64_t ext = add < 0 ? ~0ULL : 0ULL;  // sign extension
+        u128 c = (u128)w[0] + (uint64_t)add;
+        w[0] = (uint64_t)c;
+        c >>= 64;
+        for (int k = 1; k < 7; ++k) {
+            c += (u128)w[k] + ext;
+            w[k] = (uint64_t)c;
+            c >>= 64;
+        }
+    }
+    static const uint64_t k4P[7] = {0xe7fbfffffffeaaacULL, 0x7aaffffac54ffffeULL, 0x9cc34a83dac3d890ULL, 0x91dd2e13ce144afdULL,
+                                    0x2c6e9ed90d2eb35dULL, 0x680447a8e5ff9a69ULL, 0};
+    u128 c = 0;
+    for (int k = 0; k < 7; ++k) {
+        c += (u128)w[k] + k4P[k];
+        w[k] = (uint64_t)c;
+        c >>= 64;
+    }
+    Fp v;
+    for (int k = 0; k < 6; ++k) v.l[k] = w[k];  // w[6] == 0 by the magnitude bound
+    static const Fp k2_378 = {{0, 0, 0, 0, 0, 0x0400000000000000ULL}};
+    return v * k2_378;
+}
+// device XYZZ partial sum (256-byte record: X, Y, ZZ, ZZZ digits at 64-byte steps) -> Jacobian with Z = ZZ:
+// X*ZZ, Y*ZZZ, ZZ
 inline P1 p1_from_xyzz(const uint64_t* w) {
-    Fp X, Y, ZZ, ZZZ;
-    std::memcpy(X.l, w, 48);
-    std::memcpy(Y.l, w + 6, 48);
-    std::memcpy(ZZ.l, w + 12, 48);
-    std::memcpy(ZZZ.l, w + 18, 48);
-    // the device keeps coordinates lazily reduced in [0, 2p): make them canonical first
-    uint64_t br;
-    for (Fp* f : {&X, &Y, &ZZ, &ZZZ})
-        if (geq(*f, kP)) *f = raw_sub(*f, kP, br);
+    const int32_t* d = reinterpret_cast<const int32_t*>(w);
+    Fp X = fp_from_digits30(d), Y = fp_from_digits30(d + 16), ZZ = fp_from_digits30(d + 32), ZZZ = fp_from_digits30(d + 48);
     if (ZZ.is_zero()) return p1_inf();
     P1 r;
     r.x = X * ZZ;

@@ -13,9 +13,9 @@
 // (~27 us per dependent addition).  One launch, not three: every launch of a kernel with ~180 VGPRs has to
 // wait for register space next to the other slots' accumulation kernels, whether or not it finds work.
 // Inline doubling in the (rare) equal-operands branch: keeps these kernels free of scratch memory.
-#define KZG_FAST_DBL_IN_ADD 1
+
 #include "engine.h"
-#include "g1.hip.h"
+#include "g1_30.hip.h"
 
 namespace kzg {
 
@@ -64,40 +64,8 @@ static HeavyWs carve(void* base) {
     return w;
 }
 
-KZG_DEV void store_xyzz(uint4* __restrict__ out, const XYZZ& a) {
-    const Fp* f[4] = {&a.X, &a.Y, &a.ZZ, &a.ZZZ};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            uint4 v;
-            v.x = f[q]->l[4 * t];
-            v.y = f[q]->l[4 * t + 1];
-            v.z = f[q]->l[4 * t + 2];
-            v.w = f[q]->l[4 * t + 3];
-            out[q * 3 + t] = v;
-        }
-    }
-}
-KZG_DEV XYZZ load_xyzz(const uint4* __restrict__ in) {
-    XYZZ a;
-    Fp* f[4] = {&a.X, &a.Y, &a.ZZ, &a.ZZZ};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            uint4 v = in[q * 3 + t];
-            f[q]->l[4 * t] = v.x;
-            f[q]->l[4 * t + 1] = v.y;
-            f[q]->l[4 * t + 2] = v.z;
-            f[q]->l[4 * t + 3] = v.w;
-        }
-    }
-    return a;
-}
-
 // One lane per bucket: short runs are added here, long ones registered for the tree passes.
-__global__ void __launch_bounds__(64) k_bucket_finalize(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t lanes,
+__global__ void __launch_bounds__(64, 2) k_bucket_finalize(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t lanes,
                                                         const uint4* __restrict__ part_a,
                                                         const uint4* __restrict__ part_b,
                                                         uint4* __restrict__ buckets, HeavyWs ws,
@@ -129,38 +97,38 @@ __global__ void __launch_bounds__(64) k_bucket_finalize(const uint32_t* __restri
         for (uint32_t j = 0; j < en.c2; j++) ws.group_done[en.base2 + j] = 0;
         return;
     }
-    const uint4* first = first_is_b ? part_b + (size_t)l_lo * 12 : part_a + (size_t)l_lo * 12;
-    XYZZ acc = load_xyzz(first);
+    const uint4* first = first_is_b ? part_b + (size_t)l_lo * kXyzzU4 : part_a + (size_t)l_lo * kXyzzU4;
+    XYZZ30 acc = load_xyzz30(first);
     for (uint32_t l = l_lo + 1; l <= l_hi; l++) {
-        XYZZ p = load_xyzz(part_a + (size_t)l * 12);
-        xyzz_add(acc, p);
+        XYZZ30 p = load_xyzz30(part_a + (size_t)l * kXyzzU4);
+        xyzz30_add_call(&acc, &p);
     }
-    store_xyzz(buckets + (size_t)b * 12, acc);
+    store_xyzz30(buckets + (size_t)b * kXyzzU4, acc);
 }
 
 // sum of the `count` (<= 64, workgroup-uniform) accumulators held by lanes 0..count-1; result in lane 0
-KZG_DEV void tree64(XYZZ& acc, uint32_t count, u32* lds /* 48 * 64 words */) {
+__device__ __forceinline__ void tree64(XYZZ30& acc, uint32_t count, uint32_t* lds /* 52 * 64 words */) {
     const int t = threadIdx.x;
     int top = 1;
     while (top < (int)count && top < kChunk) top <<= 1;
     for (int off = top >> 1; off >= 1; off >>= 1) {
         __syncthreads();
         if (t >= off && t < 2 * off) {
-            const Fp* f[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
+            const Fq* f[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int i = 0; i < 12; i++) lds[(q * 12 + i) * kChunk + (t - off)] = f[q]->l[i];
+                for (int i = 0; i < kQ; i++) lds[(q * kQ + i) * kChunk + (t - off)] = (uint32_t)f[q]->d[i];
         }
         __syncthreads();
         if (t < off) {
-            XYZZ o;
-            Fp* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
+            XYZZ30 o;
+            Fq* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int i = 0; i < 12; i++) f[q]->l[i] = lds[(q * 12 + i) * kChunk + t];
-            xyzz_add(acc, o);
+                for (int i = 0; i < kQ; i++) f[q]->d[i] = (int32_t)lds[(q * kQ + i) * kChunk + t];
+            xyzz30_add_call(&acc, &o);
         }
     }
 }
@@ -168,68 +136,68 @@ KZG_DEV void tree64(XYZZ& acc, uint32_t count, u32* lds /* 48 * 64 words */) {
 // Work items: the chunks of 64 pieces of every registered bucket.  The last workgroup to finish a chunk of a
 // group folds the group, the last to finish a group of an entry folds the entry (release: result stored, fence,
 // counter incremented; acquire: counter seen complete, fence, results loaded).
-__global__ void __launch_bounds__(kChunk) k_heavy_tree(const uint4* __restrict__ part_a,
+__global__ void __launch_bounds__(kChunk, 2) k_heavy_tree(const uint4* __restrict__ part_a,
                                                        const uint4* __restrict__ part_b,
                                                        uint4* __restrict__ buckets, HeavyWs ws) {
-    __shared__ u32 lds[48 * kChunk];
-    __shared__ u32 s_last;
+    __shared__ uint32_t lds[4 * kQ * kChunk];
+    __shared__ uint32_t s_last;
     const uint32_t t = threadIdx.x;
     const uint32_t total = ws.counters[1];
     for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
         __syncthreads();  // s_last / lds of the previous item are no longer read
         const uint32_t slot = ws.owner1[item];
         const HeavyEntry en = ws.entries[slot];
-        uint4* const bucket = buckets + (size_t)en.bucket * 12;
+        uint4* const bucket = buckets + (size_t)en.bucket * kXyzzU4;
         // level 1: 64 pieces
         const uint32_t j = item - en.base1;
         const uint32_t first = j * kChunk;
         uint32_t count = en.span - first < (uint32_t)kChunk ? en.span - first : (uint32_t)kChunk;
-        XYZZ acc = XYZZ::inf();
+        XYZZ30 acc = xyzz30_inf();
         if (t < count) {
             const uint32_t l = en.l_lo + first + t;
-            const uint4* src = (l == en.l_lo && en.first_is_b) ? part_b + (size_t)l * 12 : part_a + (size_t)l * 12;
-            acc = load_xyzz(src);
+            const uint4* src = (l == en.l_lo && en.first_is_b) ? part_b + (size_t)l * kXyzzU4 : part_a + (size_t)l * kXyzzU4;
+            acc = load_xyzz30(src);
         }
         tree64(acc, count, lds);
         if (en.c1 == 1) {
-            if (t == 0) store_xyzz(bucket, acc);
+            if (t == 0) store_xyzz30(bucket, acc);
             continue;
         }
         // level 2: the chunk results of group g, by whoever completes it
         const uint32_t g = j / kChunk;
         const uint32_t in_group = en.c1 - g * kChunk < (uint32_t)kChunk ? en.c1 - g * kChunk : (uint32_t)kChunk;
         if (t == 0) {
-            store_xyzz(ws.tmp1 + (size_t)item * 12, acc);
+            store_xyzz30(ws.tmp1 + (size_t)item * kXyzzU4, acc);
             __threadfence();
             s_last = atomicAdd(&ws.group_done[en.base2 + g], 1u) == in_group - 1 ? 1u : 0u;
         }
         __syncthreads();
         if (!s_last) continue;
         __threadfence();
-        acc = XYZZ::inf();
-        if (t < in_group) acc = load_xyzz(ws.tmp1 + (size_t)(en.base1 + g * kChunk + t) * 12);
+        acc = xyzz30_inf();
+        if (t < in_group) acc = load_xyzz30(ws.tmp1 + (size_t)(en.base1 + g * kChunk + t) * kXyzzU4);
         tree64(acc, in_group, lds);
         if (en.c2 == 1) {
-            if (t == 0) store_xyzz(bucket, acc);
+            if (t == 0) store_xyzz30(bucket, acc);
             continue;
         }
         // level 3: the group results of the entry
         __syncthreads();
         if (t == 0) {
-            store_xyzz(ws.tmp2 + (size_t)(en.base2 + g) * 12, acc);
+            store_xyzz30(ws.tmp2 + (size_t)(en.base2 + g) * kXyzzU4, acc);
             __threadfence();
             s_last = atomicAdd(&ws.entry_done[slot], 1u) == en.c2 - 1 ? 1u : 0u;
         }
         __syncthreads();
         if (!s_last) continue;
         __threadfence();
-        acc = XYZZ::inf();
+        acc = xyzz30_inf();
         for (uint32_t i = t; i < en.c2; i += kChunk) {  // c2 <= 64 for <= 262144 segments; strided for safety
-            XYZZ p = load_xyzz(ws.tmp2 + (size_t)(en.base2 + i) * 12);
-            xyzz_add(acc, p);
+            XYZZ30 p = load_xyzz30(ws.tmp2 + (size_t)(en.base2 + i) * kXyzzU4);
+            xyzz30_add_call(&acc, &p);
         }
         tree64(acc, en.c2 < (uint32_t)kChunk ? en.c2 : (uint32_t)kChunk, lds);
-        if (t == 0) store_xyzz(bucket, acc);
+        if (t == 0) store_xyzz30(bucket, acc);
     }
 }
 

@@ -14,43 +14,11 @@
 // Field products stay inlined: measured on MI355X the call-based multiplier costs the general
 // addition 40 % (2.8 vs 1.6 G additions/s, gpurun_out microbench), the register traffic around the
 // calls outweighing the instruction-cache savings.
-#define KZG_FAST_DBL_IN_ADD 1
+
 #include "engine.h"
-#include "g1.hip.h"
+#include "g1_30.hip.h"
 
 namespace kzg {
-
-KZG_DEV XYZZ load_xyzz(const uint4* __restrict__ in) {
-    XYZZ a;
-    Fp* f[4] = {&a.X, &a.Y, &a.ZZ, &a.ZZZ};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            uint4 v = in[q * 3 + t];
-            f[q]->l[4 * t] = v.x;
-            f[q]->l[4 * t + 1] = v.y;
-            f[q]->l[4 * t + 2] = v.z;
-            f[q]->l[4 * t + 3] = v.w;
-        }
-    }
-    return a;
-}
-KZG_DEV void store_xyzz(uint4* __restrict__ out, const XYZZ& a) {
-    const Fp* f[4] = {&a.X, &a.Y, &a.ZZ, &a.ZZZ};
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            uint4 v;
-            v.x = f[q]->l[4 * t];
-            v.y = f[q]->l[4 * t + 1];
-            v.z = f[q]->l[4 * t + 2];
-            v.w = f[q]->l[4 * t + 3];
-            out[q * 3 + t] = v;
-        }
-    }
-}
 
 constexpr int kTreeBlock = 256;
 
@@ -69,8 +37,8 @@ struct TreeJobs {
     uint32_t count;
 };
 
-__global__ void __launch_bounds__(kTreeBlock) k_tree_sum(TreeJobs jobs) {
-    __shared__ u32 lds[48 * kTreeBlock];
+__global__ void __launch_bounds__(kTreeBlock, 2) k_tree_sum(TreeJobs jobs) {
+    __shared__ uint32_t lds[4 * kQ * kTreeBlock];
     const int t = threadIdx.x;
     uint32_t ji = 0;
 #pragma unroll
@@ -81,35 +49,35 @@ __global__ void __launch_bounds__(kTreeBlock) k_tree_sum(TreeJobs jobs) {
     const uint32_t gpb = kTreeBlock / lanes_per_group;
     const uint32_t g = (blockIdx.x - J.first_block) * gpb + t / lanes_per_group;
     const uint32_t l = t & (lanes_per_group - 1);
-    XYZZ acc = XYZZ::inf();
+    XYZZ30 acc = xyzz30_inf();
     if (g < J.groups) {
         const uint64_t base = (uint64_t)(g / J.inner) * J.ostride + (uint64_t)(g % J.inner) * J.gstride;
         for (uint32_t q = l; q < J.len; q += lanes_per_group) {
-            XYZZ b = load_xyzz(J.in + (size_t)(base + q * J.estride) * 12);
-            xyzz_add(acc, b);
+            XYZZ30 b = load_xyzz30(J.in + (size_t)(base + q * J.estride) * kXyzzU4);
+            xyzz30_add_call(&acc, &b);
         }
     }
     for (uint32_t off = lanes_per_group >> 1; off >= 1; off >>= 1) {
         __syncthreads();
         if (l >= off && l < 2 * off) {
-            const Fp* f[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
+            const Fq* f[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int i = 0; i < 12; i++) lds[(q * 12 + i) * kTreeBlock + (t - off)] = f[q]->l[i];
+                for (int i = 0; i < kQ; i++) lds[(q * kQ + i) * kTreeBlock + (t - off)] = (uint32_t)f[q]->d[i];
         }
         __syncthreads();
         if (l < off) {
-            XYZZ o;
-            Fp* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
+            XYZZ30 o;
+            Fq* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int i = 0; i < 12; i++) f[q]->l[i] = lds[(q * 12 + i) * kTreeBlock + t];
-            xyzz_add(acc, o);
+                for (int i = 0; i < kQ; i++) f[q]->d[i] = (int32_t)lds[(q * kQ + i) * kTreeBlock + t];
+            xyzz30_add_call(&acc, &o);
         }
     }
-    if (l == 0 && g < J.groups) store_xyzz(J.out + (size_t)g * 12, acc);
+    if (l == 0 && g < J.groups) store_xyzz30(J.out + (size_t)g * kXyzzU4, acc);
 }
 
 void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count) {

@@ -117,17 +117,6 @@ __global__ void __launch_bounds__(64) k_window_double(const uint4* __restrict__ 
     store_xyzz(out_xyzz + (size_t)i * 12, a);
 }
 
-__global__ void __launch_bounds__(64) k_affine_to_p1(const uint4* __restrict__ aff, uint32_t n, uint4* __restrict__ out) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Affine a = load_affine(aff + (size_t)i * kAffineU4);
-    uint4* o = out + (size_t)i * 9;
-    store_fp(o, fcanon(a.x));  // canonical residues for the host (blst_p1 layout)
-    store_fp(o + 3, fcanon(a.y));
-    Fp z = a.is_inf() ? Fp::zero() : Fp::one();
-    store_fp(o + 6, z);
-}
-
 // ---- fixed-base trusted setup -----------------------------------------------------------------
 constexpr int kGWindows = 32;   // 8-bit windows over a 256-bit scalar
 constexpr int kGDigits = 255;   // digits 1..255
@@ -233,9 +222,4 @@ void launch_srs_generate(hipStream_t s, const uint32_t* secret_raw8, uint64_t fi
                        (uint4*)d_xyzz_tmp);
     launch_xyzz_to_affine(s, d_xyzz_tmp, n, d_out, d_prefix);
 }
-void launch_affine_to_p1(hipStream_t s, const void* d_affine, uint32_t n, void* d_p1) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_affine_to_p1, dim3((n + 63) / 64), dim3(64), 0, s, (const uint4*)d_affine, n, (uint4*)d_p1);
-}
-
 }  // namespace kzg

@@ -4,7 +4,8 @@
 #include <stdint.h>
 #include <string.h>
 
-#include "../../kzg_poly_commit_exploration_amd/csrc/field30.hip.h"
+#include "../../kzg_poly_commit_exploration_amd/csrc/field30_inv.hip.h"
+#include "../../kzg_poly_commit_exploration_amd/csrc/g1_30.hip.h"
 
 using namespace kzg;
 
@@ -42,6 +43,29 @@ void f30_to_u32x12(const int32_t* a, uint32_t* out) {
     Fq x;
     memcpy(x.d, a, sizeof x.d);
     fq_to_u32x12(x, out);
+}
+
+void f30_inv(const int32_t* a, int32_t* r) {
+    Fq x;
+    memcpy(x.d, a, sizeof x.d);
+    Fq z = fq_inv(x);
+    memcpy(r, z.d, sizeof z.d);
+}
+// acc (X, Y, ZZ, ZZZ as 4 x 13 digits) += (px, py), negated when neg; complete group law
+void f30_madd(int32_t* acc, const int32_t* px, const int32_t* py, int neg) {
+    XYZZ30 a;
+    memcpy(a.X.d, acc, 52);
+    memcpy(a.Y.d, acc + 13, 52);
+    memcpy(a.ZZ.d, acc + 26, 52);
+    memcpy(a.ZZZ.d, acc + 39, 52);
+    Affine30 p;
+    memcpy(p.x.d, px, 52);
+    memcpy(p.y.d, py, 52);
+    xyzz30_madd(a, p, neg != 0);
+    memcpy(acc, a.X.d, 52);
+    memcpy(acc + 13, a.Y.d, 52);
+    memcpy(acc + 26, a.ZZ.d, 52);
+    memcpy(acc + 39, a.ZZZ.d, 52);
 }
 
 // the multiplier's column sums in exact arithmetic (__int128): returns the largest |column| / 2^48 seen

@@ -160,3 +160,79 @@ def test_storage_round_trip(lib):
         lib.f30_to_u32x12(d, out)
         back = sum(int(w) << (32 * i) for i, w in enumerate(out))
         assert back == s % P
+
+
+def test_inverse_safegcd(lib):
+    """fq_inv: 30 x 30 division steps; result in Montgomery form: inv(x 2^390) = x^-1 2^390"""
+    rng = random.Random(35)
+    cases = [1, 2, P - 1, P - 2, (P - 1) // 2, (P + 1) // 2, 1 << 380, 3] + [rng.randrange(1, P) for _ in range(400)]
+    for it, x in enumerate(cases):
+        v = (x * RQ) % P
+        # lazy spellings of the representative: shifted by multiples of p, negative ones included
+        v += (it % 5 - 2) * P
+        r = I13()
+        lib.f30_inv(I13(*balanced(v)), r)
+        got = value(list(r))
+        assert (got - pow(x, -1, P) * RQ) % P == 0, it
+        assert all(-(1 << 29) <= t < (1 << 29) for t in list(r)[:12])
+        assert abs(got) < 0.63 * P
+
+
+def _affine(pt):
+    """affine (x, y) ints -> Montgomery digits"""
+    return balanced((pt[0] * RQ) % P - (P if it_neg(pt[0]) else 0)), balanced((pt[1] * RQ) % P)
+
+
+def it_neg(x):
+    return x & 1  # mixes negative and positive representatives
+
+
+def _ec_add(p1, p2):
+    if p1 is None:
+        return p2
+    if p2 is None:
+        return p1
+    (x1, y1), (x2, y2) = p1, p2
+    if x1 == x2:
+        if (y1 + y2) % P == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, -1, P) % P
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, -1, P) % P
+    x3 = (lam * lam - x1 - x2) % P
+    return x3, (lam * (x1 - x3) - y1) % P
+
+
+def test_group_law_mixed_addition_complete(lib):
+    """xyzz30_madd against textbook affine arithmetic: a running sum of multiples of G with both signs, through
+    infinity, P + P (doubling branch) and P - P (cancellation)"""
+    gx = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+    gy = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+    G = (gx, gy)
+    pts = [G]
+    for _ in range(7):
+        pts.append(_ec_add(pts[-1], G))  # G .. 8G
+    I52 = ctypes.c_int32 * 52
+    acc = I52()
+    want = None
+    rng = random.Random(36)
+    # script: (index into pts, negate); includes G + G, then -2G twice to pass through infinity, etc.
+    script = [(0, 0), (0, 0), (1, 1), (1, 1), (1, 0), (2, 0), (4, 1), (0, 0), (0, 1), (7, 0)] + \
+             [(rng.randrange(8), rng.randrange(2)) for _ in range(200)]
+    for idx, neg in script:
+        px, py = _affine(pts[idx])
+        lib.f30_madd(acc, I13(*px), I13(*py), neg)
+        q = pts[idx] if not neg else (pts[idx][0], (-pts[idx][1]) % P)
+        want = _ec_add(want, q)
+        X, Y, ZZ, ZZZ = (value(list(acc)[13 * k:13 * k + 13]) for k in range(4))
+        if want is None:
+            assert ZZ == 0
+            continue
+        assert ZZ % P != 0
+        rinv = pow(RQ, -1, P)
+        x = X * pow(ZZ, -1, P) % P  # the Montgomery factors cancel in the quotient
+        y = Y * pow(ZZZ, -1, P) % P
+        assert (x, y) == want
+        assert (ZZ * rinv) ** 3 % P == (ZZZ * rinv) ** 2 % P
+        for val, bound in ((X, 2.6), (Y, 1.4), (ZZ, 0.7), (ZZZ, 0.7)):
+            assert abs(val) < bound * P

@@ -692,6 +692,127 @@ def test_failed_workspace_allocation_leaves_no_half_ready_context(oracle, golden
         eng.close()
 
 
+# ---------------------------------------------------------------- multi-device context (kzg_ctx_create_multi)
+
+def _device_lists():
+    """device lists for the multi-device tests: virtual slices on device 0 always; every visible device when there is
+    more than one (the driver's 8-GPU node; a one-GPU box only has the virtual form)"""
+    import torch
+
+    lists = [[0, 0, 0, 0], [0, 0, 0]]
+    if torch.cuda.device_count() > 1:
+        lists.append(list(range(torch.cuda.device_count())))
+    return lists
+
+
+def test_multi_device_context_commit_and_open(engines, oracle, golden):
+    """One context over several devices: SRS split by point range, commit and open sharded transparently (range-
+    sharded opening with the carry recurrence on the host), partial sums gathered and added.  Same bytes as the golden
+    vectors / the single-device engine, including shorter polynomials (empty slices), the degree boundary and the
+    reference's three error texts."""
+    secret = bytes.fromhex(golden["secret_be"])
+    d = 2500
+    c, z, y = _bench_poly(oracle, d)
+    case = _case(golden, d)
+    for devs in _device_lists():
+        eng = K.Engine(devices=devs)
+        try:
+            assert eng.num_devices() == len(devs)
+            eng.srs_generate(secret, d + 1)
+            assert eng.srs_len() == d + 1
+            # SRS read-back across slice boundaries
+            per = (d + 1 + len(devs) - 1) // len(devs)
+            got = eng.srs_read(per - 2, 5)
+            for k in range(5):
+                assert oracle.p1_compress(got[k]) == oracle.p1_compress(oracle.srs_g1_at(per - 2 + k, secret))
+            assert eng.commit_limbs(c).compress().hex() == case["commit"]
+            assert eng.open_limbs(c, z, y).compress().hex() == case["proof"]
+            # shorter polynomials: the upper slices receive nothing
+            for dd in (1, 100, 1000):
+                cc, zz, yy = _bench_poly(oracle, dd)
+                cs = _case(golden, dd)
+                assert eng.commit_limbs(cc).compress().hex() == cs["commit"], (devs, dd)
+                assert eng.open_limbs(cc, zz, yy).compress().hex() == cs["proof"], (devs, dd)
+            # trailing zeros beyond the SRS are not a degree error; a non-zero coefficient there is
+            longer = np.concatenate([c, np.zeros((7, 4), dtype=np.uint64)])
+            assert eng.commit_limbs(longer).compress().hex() == case["commit"]
+            assert eng.open_limbs(longer, z, y).compress().hex() == case["proof"]
+            longer[-1, 0] = 1
+            with pytest.raises(K.KzgError) as ei:
+                eng.commit_limbs(longer)
+            assert ei.value.status == K.KZG_ERR_DEGREE_TOO_HIGH
+            # degree d + 1 can still be OPENED on d + 1 points (the quotient has degree d) but not committed
+            c1 = oracle.bench_coefficients(d + 2)
+            z1 = K.Scalar.from_limbs(oracle.bench_input_point(d + 1))
+            y1 = K.Scalar.from_limbs(oracle.poly_evaluate(c1, oracle.fr_from_int(z1.v)))
+            single = engines.bench_srs(d + 1)
+            assert eng.open_limbs(c1, z1, y1).compress() == single.open_limbs(c1, z1, y1).compress()
+            # the reference's error order: remainder before degree, constant polynomial, empty polynomial
+            with pytest.raises(K.KzgError) as ei:
+                eng.open_limbs(c, z, K.Scalar(y.v + 1))
+            assert ei.value.status == K.KZG_ERR_REMAINDER
+            const = K.scalars_to_limbs([7] + [0] * 40)
+            assert eng.open_limbs(const, z, K.Scalar(7)).is_infinity()
+            with pytest.raises(K.KzgError) as ei:
+                eng.open_limbs(const, z, K.Scalar(8))
+            assert ei.value.status == K.KZG_ERR_CONSTANT_POLY
+            assert eng.commit_limbs(np.zeros((0, 4), dtype=np.uint64)).is_infinity()
+            # random i128-like inputs against the single-device engine
+            rnd = random.Random(2024)
+            p = K.scalars_to_limbs([rnd.randrange(-(1 << 127), 1 << 127) for _ in range(d + 1)])
+            zz = K.Scalar(rnd.randrange(K.R_MODULUS))
+            yy = eng.evaluate_limbs(p, zz)
+            assert eng.commit_limbs(p).compress() == single.commit_limbs(p).compress()
+            assert eng.open_limbs(p, zz, yy).compress() == single.open_limbs(p, zz, yy).compress()
+            # asynchronous / device-pointer entry points belong to one device
+            with pytest.raises(K.KzgError) as ei:
+                eng.dev_alloc(64)
+            assert ei.value.status == K.KZG_ERR_INVALID_ARG
+            if len(set(devs)) == len(devs) and len(devs) > 1:
+                assert eng.rccl_exchanges() > 0  # distinct devices: the partials went through ncclAllGather
+            else:
+                assert eng.rccl_exchanges() == 0
+        finally:
+            eng.close()
+
+
+def test_multi_device_context_exchange_over_rccl_world_of_one(oracle, golden, monkeypatch):
+    """The RCCL leg of the exchange (ncclCommInitAll, grouped ncclAllGather on the context's streams, download, sum)
+    on a communicator of ONE device: all a one-GPU box can form.  Distinct devices take exactly this code."""
+    monkeypatch.setenv("KZG_MULTI_FORCE_RCCL", "1")
+    secret = bytes.fromhex(golden["secret_be"])
+    d = 1000
+    c, z, y = _bench_poly(oracle, d)
+    case = _case(golden, d)
+    eng = K.Engine(devices=[0])
+    try:
+        eng.srs_generate(secret, d + 1)
+        assert eng.commit_limbs(c).compress().hex() == case["commit"]
+        assert eng.open_limbs(c, z, y).compress().hex() == case["proof"]
+        assert eng.rccl_exchanges() == 2
+    finally:
+        eng.close()
+
+
+def test_multi_device_context_degree_2_20(oracle, golden):
+    """BASELINE config 4's shape on the devices at hand: one degree-2^20 commitment and opening sharded over 4 slices"""
+    import torch
+
+    secret = bytes.fromhex(golden["secret_be"])
+    d = 1 << 20
+    c, z, y = _bench_poly(oracle, d)
+    case = _case(golden, d)
+    ndev = torch.cuda.device_count()
+    devs = list(range(ndev)) if ndev > 1 else [0, 0, 0, 0]
+    eng = K.Engine(devices=devs)
+    try:
+        eng.srs_generate(secret, d + 1)
+        assert eng.commit_limbs(c).compress().hex() == case["commit"]
+        assert eng.open_limbs(c, z, y).compress().hex() == case["proof"]
+    finally:
+        eng.close()
+
+
 # ---------------------------------------------------------------- 2^20 (BASELINE config 3, the bench workload)
 
 def test_degree_2_20_commit_and_proof_golden(engines, oracle, golden):

@@ -51,3 +51,14 @@ def test_create_polynomial_with_tailing_zeros():
     assert K.Polynomial.try_from([]).degree() == 0
     p = K.Polynomial.from_limbs(K.scalars_to_limbs([1, 0, 1, 0, 0]))
     assert p.degree() == 2 and [c.v for c in p.coefficients()] == [1, 0, 1]
+
+
+def test_fips_asm_groups_match_their_generator():
+    """the hand-scheduled multiply-add groups of csrc/field_fips.hip.h are generated: tools/gen_fips_groups.py --check"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_fips_groups.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout

@@ -33,6 +33,19 @@ if __name__ == "__main__":
     with open(out, "w") as f:
         f.write("// 2^384 mod p, balanced radix-2^30 digits (tools/gen_field30_constants.py)\n" + fmt(balanced(c384)) + "\n")
     print("wrote", os.path.normpath(out))
+    def emit(name, comment, digits):
+        path = os.path.join(here, "..", "kzg_poly_commit_exploration_amd", "csrc", name)
+        with open(path, "w") as f:
+            f.write("// " + comment + " (tools/gen_field30_constants.py)\n" + fmt(digits) + "\n")
+        print("wrote", os.path.normpath(path))
+
+    def centered(v):
+        v %= P
+        return v - P if v > P // 2 else v
+
+    emit("field30_p_u30.inc", "p, unsigned radix-2^30 digits", [(P >> (B * i)) & ((1 << B) - 1) for i in range(N)])
+    emit("field30_c1170.inc", "2^1170 mod p, balanced radix-2^30 digits: turns v^-1 into the Montgomery form of the inverse",
+         balanced(centered(pow(2, 1170, P))))
     one = pow(2, 390, P)
     if one > P // 2:
         one -= P

@@ -601,16 +601,16 @@ static int run_field30() {
                         0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
     const u32 GY[12] = {0x0ce72271u, 0xbaac93d5u, 0x7918fd8eu, 0x8c22631au, 0x570725ceu, 0xdd595f13u,
                         0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
-    u32 h[128], h2[128];
+    u32 h[128], h2[128], hin[128];
     u32* dio;
     u64* out;
     CHECK(hipMalloc(&dio, sizeof h));
     CHECK(hipMalloc(&out, sizeof(u64) * 256 * 8 * 1024));
     auto reset = [&] {
-        memset(h, 0, sizeof h);
-        memcpy(h, GX, 48);
-        memcpy(h + 12, GY, 48);
-        CHECK(hipMemcpy(dio, h, sizeof h, hipMemcpyHostToDevice));
+        memset(hin, 0, sizeof hin);
+        memcpy(hin, GX, 48);
+        memcpy(hin + 12, GY, 48);
+        CHECK(hipMemcpy(dio, hin, sizeof hin, hipMemcpyHostToDevice));
     };
     // correctness first: the same short loops through both representations
     reset();
