@@ -68,39 +68,34 @@ inline Fp neg(const Fp& a) {
     uint64_t br;
     return a.is_zero() ? a : raw_sub(kP, a, br);
 }
-// Separated operand-scanning product followed by a word-by-word Montgomery reduction (REDC).
+// Montgomery product a * b / 2^384 mod p, coarsely integrated operand scanning (CIOS), fully unrolled by the
+// compiler.  Accepts any a < 2^384 and b < p (the result of an unreduced addition may enter as a).
 inline Fp operator*(const Fp& a, const Fp& b) {
-    uint64_t w[13] = {0};
-    uint64_t hi_carry = 0;
+    uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 6; ++i) {
         u128 c = 0;
         for (int j = 0; j < 6; ++j) {
-            c += (u128)a.l[j] * b.l[i] + w[i + j];
-            w[i + j] = (uint64_t)c;
+            c += (u128)a.l[j] * b.l[i] + t[j];
+            t[j] = (uint64_t)c;
             c >>= 64;
         }
-        w[i + 6] = (uint64_t)c;
+        c += t[6];
+        t[6] = (uint64_t)c;
+        t[7] = (uint64_t)(c >> 64);
+        const uint64_t m = t[0] * kN0;
+        c = ((u128)m * kP.l[0] + t[0]) >> 64;
+        for (int j = 1; j < 6; ++j) {
+            c += (u128)m * kP.l[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[6];
+        t[5] = (uint64_t)c;
+        t[6] = t[7] + (uint64_t)(c >> 64);
     }
-    for (int i = 0; i < 6; ++i) {
-        uint64_t m = w[i] * kN0;
-        u128 c = 0;
-        for (int j = 0; j < 6; ++j) {
-            c += (u128)m * kP.l[j] + w[i + j];
-            w[i + j] = (uint64_t)c;
-            c >>= 64;
-        }
-        // propagate into the upper words
-        for (int k = i + 6; c != 0 && k < 12; ++k) {
-            c += w[k];
-            w[k] = (uint64_t)c;
-            c >>= 64;
-        }
-        hi_carry += (uint64_t)c;
-    }
-    Fp r;
-    for (int i = 0; i < 6; ++i) r.l[i] = w[6 + i];
+    Fp r = {{t[0], t[1], t[2], t[3], t[4], t[5]}};
     uint64_t br;
-    if (hi_carry || geq(r, kP)) r = raw_sub(r, kP, br);
+    if (t[6] || geq(r, kP)) r = raw_sub(r, kP, br);
     return r;
 }
 inline Fp sqr(const Fp& a) { return a * a; }

@@ -3,11 +3,11 @@
 // Restates Evaluation::verify_proof (reference src/polynomial.rs:276-294), which the reference delegates to
 // blst's Miller loop + final exponentiation (src/curves.rs:355-371):
 //        e(proof, [s]G2 - [z]G2) == e(commitment - [y]G1, G2).
-// two pairings per proof, constant cost, host side.  Written for obviousness, not speed
-// (~35 ms per check; blst needs ~1.5 ms): Fp12 = Fp[w]/(w^12 - 2w^6 + 2) with schoolbook products, G2 arithmetic in
-// affine Fp2 coordinates on the twist y^2 = x^3 + 4(u+1), Miller loop over |x| = 0xd201000000010000 with affine line
-// functions, ONE shared generic exponentiation by (p^12 - 1)/r.  The check is rearranged so that every scalar
-// multiplication happens in G1:
+// two pairings per proof, constant cost, host side.  Tower Fp2 -> Fp6 -> Fp12 (w^6 = 1 + u),
+// ONE Miller loop over |x| = 0xd201000000010000 for both pairings (shared squaring, division-free projective line
+// functions on the twist y^2 = x^3 + 4(u+1), sparse 0-1-4 products), final exponentiation = easy part + five
+// exponentiations by |x| with Granger-Scott cyclotomic squarings.  ~25 000 base-field products per check.
+// The check is rearranged so that every scalar multiplication happens in G1:
 //        e(proof, [s]G2) * e(-([z]proof + commitment - [y]G1), G2) == 1,
 // which accepts exactly the same (commitment, proof, z, y) as the reference's equation (bilinearity).
 // Any non-degenerate bilinear pairing decides the equation, so the sign of the BLS parameter and scalings of the
@@ -89,144 +89,273 @@ inline G2Affine g2_from_p2(const uint64_t* w) {
     return q;
 }
 
-// ---- Fp12 = Fp[w] / (w^12 - 2 w^6 + 2);  Fp2 sits inside through u = w^6 - 1 ---------------------
-struct F12 {
-    Fp c[12];
+// ---- tower Fp2 -> Fp6 = Fp2[v]/(v^3 - xi) -> Fp12 = Fp6[w]/(w^2 - v), xi = 1 + u -----------------------------
+// (so w^6 = xi: an element is sum_{i<6} a_i w^i with a_i in Fp2; c0 = (a0, a2, a4), c1 = (a1, a3, a5))
+inline Fp2 fp2_mul(const Fp2& x, const Fp2& y) {  // Karatsuba: 3 base-field products
+    const Fp t0 = x.a * y.a, t1 = x.b * y.b;
+    return {t0 - t1, (x.a + x.b) * (y.a + y.b) - t0 - t1};
+}
+inline Fp2 fp2_sqr(const Fp2& x) {  // (a + b)(a - b), 2ab
+    const Fp ab = x.a * x.b;
+    return {(x.a + x.b) * (x.a - x.b), ab + ab};
+}
+inline Fp2 fp2_mul_xi(const Fp2& x) { return {x.a - x.b, x.a + x.b}; }  // (a + bu)(1 + u)
+inline Fp2 fp2_conj(const Fp2& x) { return {x.a, neg(x.b)}; }
+inline Fp2 fp2_dbl(const Fp2& x) { return x + x; }
+inline Fp2 fp2_zero() { return {fp_zero(), fp_zero()}; }
+inline Fp2 fp2_one() { return {kOne, fp_zero()}; }
+
+struct Fp6 {
+    Fp2 c0, c1, c2;
 };
-inline F12 f12_zero() {
-    F12 r;
-    std::memset(&r, 0, sizeof r);
+inline Fp6 operator+(const Fp6& x, const Fp6& y) { return {x.c0 + y.c0, x.c1 + y.c1, x.c2 + y.c2}; }
+inline Fp6 operator-(const Fp6& x, const Fp6& y) { return {x.c0 - y.c0, x.c1 - y.c1, x.c2 - y.c2}; }
+inline Fp6 fp6_neg(const Fp6& x) { return {fp2_neg(x.c0), fp2_neg(x.c1), fp2_neg(x.c2)}; }
+inline Fp6 fp6_mul_v(const Fp6& x) { return {fp2_mul_xi(x.c2), x.c0, x.c1}; }
+inline Fp6 fp6_mul(const Fp6& a, const Fp6& b) {  // Karatsuba, 6 Fp2 products
+    const Fp2 t0 = fp2_mul(a.c0, b.c0), t1 = fp2_mul(a.c1, b.c1), t2 = fp2_mul(a.c2, b.c2);
+    Fp6 r;
+    r.c0 = t0 + fp2_mul_xi(fp2_mul(a.c1 + a.c2, b.c1 + b.c2) - t1 - t2);
+    r.c1 = fp2_mul(a.c0 + a.c1, b.c0 + b.c1) - t0 - t1 + fp2_mul_xi(t2);
+    r.c2 = fp2_mul(a.c0 + a.c2, b.c0 + b.c2) - t0 - t2 + t1;
     return r;
 }
+inline Fp6 fp6_mul_by_01(const Fp6& a, const Fp2& b0, const Fp2& b1) {  // a * (b0 + b1 v)
+    return {fp2_mul(a.c0, b0) + fp2_mul_xi(fp2_mul(a.c2, b1)), fp2_mul(a.c0, b1) + fp2_mul(a.c1, b0),
+            fp2_mul(a.c1, b1) + fp2_mul(a.c2, b0)};
+}
+inline Fp6 fp6_mul_by_1(const Fp6& a, const Fp2& b1) {  // a * (b1 v)
+    return {fp2_mul_xi(fp2_mul(a.c2, b1)), fp2_mul(a.c0, b1), fp2_mul(a.c1, b1)};
+}
+inline Fp6 fp6_inv(const Fp6& a) {
+    const Fp2 c0 = fp2_sqr(a.c0) - fp2_mul_xi(fp2_mul(a.c1, a.c2));
+    const Fp2 c1 = fp2_mul_xi(fp2_sqr(a.c2)) - fp2_mul(a.c0, a.c1);
+    const Fp2 c2 = fp2_sqr(a.c1) - fp2_mul(a.c0, a.c2);
+    const Fp2 t = fp2_inv(fp2_mul(a.c0, c0) + fp2_mul_xi(fp2_mul(a.c2, c1) + fp2_mul(a.c1, c2)));
+    return {fp2_mul(c0, t), fp2_mul(c1, t), fp2_mul(c2, t)};
+}
+
+struct F12 {
+    Fp6 c0, c1;
+};
 inline F12 f12_one() {
-    F12 r = f12_zero();
-    r.c[0] = kOne;
+    F12 r;
+    std::memset(&r, 0, sizeof r);
+    r.c0.c0.a = kOne;
     return r;
 }
 inline bool f12_is_one(const F12& x) {
-    if (!(x.c[0] == kOne)) return false;
-    for (int i = 1; i < 12; ++i)
-        if (!x.c[i].is_zero()) return false;
-    return true;
+    const F12 one = f12_one();
+    return std::memcmp(&x, &one, sizeof x) == 0;  // base-field values are canonical
 }
-inline F12 operator*(const F12& x, const F12& y) {
-    Fp t[23];
-    for (auto& v : t) v = fp_zero();
-    for (int i = 0; i < 12; ++i) {
-        if (x.c[i].is_zero()) continue;
-        for (int j = 0; j < 12; ++j) {
-            if (y.c[j].is_zero()) continue;
-            t[i + j] = t[i + j] + x.c[i] * y.c[j];
+inline F12 operator*(const F12& a, const F12& b) {  // 3 Fp6 products
+    const Fp6 t0 = fp6_mul(a.c0, b.c0), t1 = fp6_mul(a.c1, b.c1);
+    return {t0 + fp6_mul_v(t1), fp6_mul(a.c0 + a.c1, b.c0 + b.c1) - t0 - t1};
+}
+inline F12 f12_sqr(const F12& a) {  // complex squaring, 2 Fp6 products
+    const Fp6 ab = fp6_mul(a.c0, a.c1);
+    return {fp6_mul(a.c0 + a.c1, a.c0 + fp6_mul_v(a.c1)) - ab - fp6_mul_v(ab), ab + ab};
+}
+inline F12 f12_conj(const F12& a) { return {a.c0, fp6_neg(a.c1)}; }  // the p^6 Frobenius; the inverse on the cyclotomic subgroup
+inline F12 f12_inv(const F12& a) {
+    const Fp6 t = fp6_inv(fp6_mul(a.c0, a.c0) - fp6_mul_v(fp6_mul(a.c1, a.c1)));
+    return {fp6_mul(a.c0, t), fp6_neg(fp6_mul(a.c1, t))};
+}
+// a * (l0 + l1 v + l4 v w): the shape of every Miller-loop line (sparse "0-1-4" product, 13 Fp2 products)
+inline F12 f12_mul_by_014(const F12& a, const Fp2& l0, const Fp2& l1, const Fp2& l4) {
+    const Fp6 t0 = fp6_mul_by_01(a.c0, l0, l1), t1 = fp6_mul_by_1(a.c1, l4);
+    return {fp6_mul_v(t1) + t0, fp6_mul_by_01(a.c0 + a.c1, l0, l1 + l4) - t0 - t1};
+}
+// Granger-Scott squaring: valid for elements of the cyclotomic subgroup (after the easy part of the final
+// exponentiation), 9 Fp2 squarings' worth instead of 12 Fp2 products
+inline void fp4_sqr(const Fp2& a, const Fp2& b, Fp2& t0, Fp2& t1) {  // (a + b y)^2, y^2 = xi
+    const Fp2 ab = fp2_mul(a, b);
+    t0 = fp2_mul(a + b, fp2_mul_xi(b) + a) - ab - fp2_mul_xi(ab);
+    t1 = ab + ab;
+}
+inline F12 f12_cyclotomic_sqr(const F12& f) {
+    const Fp2 &r0 = f.c0.c0, &r4 = f.c0.c1, &r3 = f.c0.c2, &r2 = f.c1.c0, &r1 = f.c1.c1, &r5 = f.c1.c2;
+    Fp2 t0, t1, t2, t3, t4, t5;
+    fp4_sqr(r0, r1, t0, t1);
+    fp4_sqr(r2, r3, t2, t3);
+    fp4_sqr(r4, r5, t4, t5);
+    F12 z;
+    auto three_minus_two = [](const Fp2& t, const Fp2& r) { const Fp2 d = t - r; return d + d + t; };  // 3t - 2r
+    auto three_plus_two = [](const Fp2& t, const Fp2& r) { const Fp2 d = t + r; return d + d + t; };    // 3t + 2r
+    z.c0.c0 = three_minus_two(t0, r0);
+    z.c1.c1 = three_plus_two(t1, r1);
+    z.c1.c0 = three_plus_two(fp2_mul_xi(t5), r2);
+    z.c0.c2 = three_minus_two(t4, r3);
+    z.c0.c1 = three_minus_two(t2, r4);
+    z.c1.c2 = three_plus_two(t3, r5);
+    return z;
+}
+// Frobenius x -> x^p: every Fp2 coefficient is conjugated and the coefficient of w^i picks up gamma^i with
+// gamma = w^(p-1) = xi^((p-1)/6) in Fp2 (computed once)
+inline const Fp2* frobenius_gammas() {
+    static Fp2 g[6];
+    static bool ready = false;
+    if (!ready) {
+        // (p - 1) / 6 from kP: p - 1 is divisible by 6
+        uint64_t q[6], rem = 0;
+        Fp pm1 = kP;
+        pm1.l[0] -= 1;
+        for (int i = 5; i >= 0; --i) {
+            u128 cur = ((u128)rem << 64) | pm1.l[i];
+            q[i] = (uint64_t)(cur / 6);
+            rem = (uint64_t)(cur % 6);
         }
+        Fp2 base = {kOne, kOne}, acc = fp2_one();  // xi = 1 + u
+        for (int i = 0; i < 384; ++i) {
+            if ((q[i >> 6] >> (i & 63)) & 1) acc = fp2_mul(acc, base);
+            base = fp2_sqr(base);
+        }
+        g[0] = fp2_one();
+        for (int i = 1; i < 6; ++i) g[i] = fp2_mul(g[i - 1], acc);
+        ready = true;
     }
-    for (int k = 22; k >= 12; --k) {  // w^12 = 2 w^6 - 2
-        Fp v2 = t[k] + t[k];
-        t[k - 6] = t[k - 6] + v2;
-        t[k - 12] = t[k - 12] - v2;
-    }
+    return g;
+}
+inline F12 f12_frobenius(const F12& a) {
+    const Fp2* g = frobenius_gammas();
     F12 r;
-    for (int i = 0; i < 12; ++i) r.c[i] = t[i];
+    r.c0.c0 = fp2_conj(a.c0.c0);                    // w^0
+    r.c1.c0 = fp2_mul(fp2_conj(a.c1.c0), g[1]);     // w^1
+    r.c0.c1 = fp2_mul(fp2_conj(a.c0.c1), g[2]);     // w^2
+    r.c1.c1 = fp2_mul(fp2_conj(a.c1.c1), g[3]);     // w^3
+    r.c0.c2 = fp2_mul(fp2_conj(a.c0.c2), g[4]);     // w^4
+    r.c1.c2 = fp2_mul(fp2_conj(a.c1.c2), g[5]);     // w^5
     return r;
 }
 
-inline F12 f12_sqr(const F12& x) {  // cross products once: 78 instead of 144 field products
-    Fp t[23];
-    for (auto& v : t) v = fp_zero();
-    for (int i = 0; i < 12; ++i) {
-        if (x.c[i].is_zero()) continue;
-        t[2 * i] = t[2 * i] + x.c[i] * x.c[i];
-        for (int j = i + 1; j < 12; ++j) {
-            if (x.c[j].is_zero()) continue;
-            Fp p = x.c[i] * x.c[j];
-            t[i + j] = t[i + j] + p + p;
-        }
-    }
-    for (int k = 22; k >= 12; --k) {
-        Fp v2 = t[k] + t[k];
-        t[k - 6] = t[k - 6] + v2;
-        t[k - 12] = t[k - 12] - v2;
-    }
-    F12 r;
-    for (int i = 0; i < 12; ++i) r.c[i] = t[i];
-    return r;
+// ---- Miller loop ---------------------------------------------------------------------------------
+// T on the twist in homogeneous projective coordinates (x = X/Z, y = Y/Z), P = (xp, yp) in G1.  With slope
+// lambda the line through T (tangent, or chord to Q) evaluated at P and scaled by w^3 is
+//        (y_T - lambda x_T) + (lambda xp) w^2 - yp w^3 ;
+// multiplied by the slope's denominator (an element of Fp2, which the final exponentiation kills) it has no
+// division:  tangent  (2Y^2 Z - 3X^3) + (3 X^2 Z xp) w^2 - (2 Y Z^2 yp) w^3
+//            chord    (y_Q mu - theta x_Q) + (theta xp) w^2 - (mu yp) w^3,   theta = y_Q Z - Y, mu = x_Q Z - X.
+struct G2Proj {
+    Fp2 X, Y, Z;
+};
+struct LineCoeffs {
+    Fp2 l0, l1, l4;  // coefficients of w^0, w^2 (= v), w^3 (= v w)
+};
+inline LineCoeffs miller_double(G2Proj& t, const Fp& xp, const Fp& yp) {
+    const Fp2 XX = fp2_sqr(t.X), YY = fp2_sqr(t.Y), ZZ = fp2_sqr(t.Z);
+    const Fp2 X3 = fp2_mul(XX, t.X);
+    const Fp2 W = XX + XX + XX;                 // 3X^2
+    LineCoeffs l;
+    l.l0 = fp2_dbl(fp2_mul(YY, t.Z)) - (X3 + X3 + X3);
+    l.l1 = fp2_scale(fp2_mul(W, t.Z), xp);
+    l.l4 = fp2_neg(fp2_scale(fp2_dbl(fp2_mul(t.Y, ZZ)), yp));
+    // doubling (a = 0, homogeneous): s = 2YZ, B = 2 X Y s, h = W^2 - 2B
+    const Fp2 S = fp2_dbl(fp2_mul(t.Y, t.Z));
+    const Fp2 R = fp2_mul(t.Y, S);
+    const Fp2 B = fp2_dbl(fp2_mul(t.X, R));
+    const Fp2 H = fp2_sqr(W) - fp2_dbl(B);
+    const Fp2 RR = fp2_sqr(R);
+    const Fp2 SS = fp2_sqr(S);
+    t.Y = fp2_mul(W, B - H) - fp2_dbl(RR);
+    t.X = fp2_mul(H, S);
+    t.Z = fp2_mul(S, SS);
+    return l;
 }
-
-// Line through T1, T2 (T1 == T2: tangent) on the twist with slope lambda, evaluated at the G1 point (xp, yp) and
-// scaled by w^3 (an element of Fp4):  (y1 - lambda x1) + (lambda xp) w^2 - yp w^3,  Fp2 embedded as (a - b) + b w^6.
-inline F12 line_value(const Fp2& lambda, const Fp2& x1, const Fp2& y1, const Fp& xp, const Fp& yp) {
-    F12 l = f12_zero();
-    Fp2 c0 = y1 - lambda * x1;
-    Fp2 c2 = fp2_scale(lambda, xp);
-    l.c[0] = c0.a - c0.b;
-    l.c[6] = c0.b;
-    l.c[2] = c2.a - c2.b;
-    l.c[8] = c2.b;
-    l.c[3] = neg(yp);
+inline LineCoeffs miller_add(G2Proj& t, const G2Affine& q, const Fp& xp, const Fp& yp) {
+    const Fp2 theta = fp2_mul(q.y, t.Z) - t.Y;  // slope numerator
+    const Fp2 mu = fp2_mul(q.x, t.Z) - t.X;     // slope denominator
+    LineCoeffs l;
+    l.l0 = fp2_mul(q.y, mu) - fp2_mul(theta, q.x);
+    l.l1 = fp2_scale(theta, xp);
+    l.l4 = fp2_neg(fp2_scale(mu, yp));
+    // mixed addition (madd-1998-cmo): u = theta, v = mu
+    const Fp2 vv = fp2_sqr(mu), vvv = fp2_mul(vv, mu);
+    const Fp2 Rr = fp2_mul(vv, t.X);
+    const Fp2 A = fp2_mul(fp2_sqr(theta), t.Z) - vvv - fp2_dbl(Rr);
+    t.Y = fp2_mul(theta, Rr - A) - fp2_mul(vvv, t.Y);
+    t.X = fp2_mul(mu, A);
+    t.Z = fp2_mul(vvv, t.Z);
     return l;
 }
 
-// f_{|x|, Q}(P) without the final exponentiation; 1 when either argument is infinity.  ok = false if the loop
-// meets a vertical line (cannot happen for points of order r).
-inline F12 miller_loop(const G2Affine& q, const P1& p_jac, bool& ok) {
+// prod_k f_{|x|, Q_k}(P_k) without the final exponentiation, one shared squaring per loop step; pairs with a
+// point at infinity contribute 1.  ok = false if a chord degenerates (cannot happen for points of order r).
+struct MillerPair {
+    G2Affine q;
+    Fp xp, yp;
+    G2Proj t;
+    bool live;
+};
+inline F12 multi_miller_loop(const G2Affine* qs, const P1* ps, int count, bool& ok) {
     ok = true;
-    if (q.inf || p_jac.is_inf()) return f12_one();
-    P1 pa = p1_normalize(p_jac);
-    const Fp xp = pa.x, yp = pa.y;
+    MillerPair pr[4];
+    for (int k = 0; k < count; ++k) {
+        pr[k].live = !(qs[k].inf || ps[k].is_inf());
+        if (!pr[k].live) continue;
+        const P1 pa = p1_normalize(ps[k]);
+        pr[k].q = qs[k];
+        pr[k].xp = pa.x;
+        pr[k].yp = pa.y;
+        pr[k].t = {qs[k].x, qs[k].y, fp2_one()};
+    }
     const uint64_t ate = 0xd201000000010000ULL;
-    Fp2 tx = q.x, ty = q.y;
     F12 f = f12_one();
-    Fp three = kOne + kOne + kOne;
     for (int i = 62; i >= 0; --i) {  // bit 63 is the leading one
-        if (ty.is_zero()) { ok = false; return f12_one(); }
-        Fp2 lambda = fp2_scale(tx * tx, three) * fp2_inv(ty + ty);
-        f = f12_sqr(f) * line_value(lambda, tx, ty, xp, yp);
-        Fp2 nx = lambda * lambda - tx - tx;
-        ty = lambda * (tx - nx) - ty;
-        tx = nx;
+        f = f12_sqr(f);
+        for (int k = 0; k < count; ++k) {
+            if (!pr[k].live) continue;
+            if (pr[k].t.Y.is_zero() || pr[k].t.Z.is_zero()) { ok = false; return f12_one(); }
+            const LineCoeffs l = miller_double(pr[k].t, pr[k].xp, pr[k].yp);
+            f = f12_mul_by_014(f, l.l0, l.l1, l.l4);
+        }
         if ((ate >> i) & 1) {
-            if (tx == q.x) { ok = false; return f12_one(); }
-            Fp2 lam = (q.y - ty) * fp2_inv(q.x - tx);
-            f = f * line_value(lam, tx, ty, xp, yp);
-            Fp2 ax = lam * lam - tx - q.x;
-            ty = lam * (tx - ax) - ty;
-            tx = ax;
+            for (int k = 0; k < count; ++k) {
+                if (!pr[k].live) continue;
+                const LineCoeffs l = miller_add(pr[k].t, pr[k].q, pr[k].xp, pr[k].yp);
+                if (pr[k].t.Z.is_zero()) { ok = false; return f12_one(); }
+                f = f12_mul_by_014(f, l.l0, l.l1, l.l4);
+            }
         }
     }
     return f;
 }
 
-inline F12 f12_final_exp(const F12& x) {  // x^((p^12 - 1) / r), 4314-bit exponent, 4-bit fixed windows
-    static const char* kExp =
-        "2ee1db5dcc825b7e1bda9c0496a1c0a89ee0193d4977b3f7d4507d07363baa13f8d14a917848517badc3a43d1073776a"
-        "b353f2c30698e8cc7deada9c0aadff5e9cfee9a074e43b9a660835cc872ee83ff3a0f0f1c0ad0d6106feaf4e347aa68a"
-        "d49466fa927e7bb9375331807a0dce2630d9aa4b113f414386b0e8819328148978e2b0dd39099b86e1ab656d2670d93e"
-        "4d7acdd350da5359bc73ab61a0c5bf24c374693c49f570bcd2b01f3077ffb10bf24dde41064837f27611212596bc293c"
-        "8d4c01f25118790f4684d0b9c40a68eb74bb22a40ee7169cdc1041296532fef459f12438dfc8e2886ef965e61a474c5c"
-        "85b0129127a1b5ad0463434724538411d1676a53b5a62eb34c05739334f46c02c3f0bd0c55d3109cd15948d0a1fad200"
-        "44ce6ad4c6bec3ec03ef19592004cedd556952c6d8823b19dadd7c2498345c6e5308f1c511291097db60b1749bf9b71a"
-        "9f9e0100418a3ef0bc627751bbd81367066bca6a4c1b6dcfc5cceb73fc56947a403577dfa9e13c24ea820b09c1d9f7c3"
-        "1759c3635de3f7a3639991708e88adce88177456c49637fd7961be1a4c7e79fb02faa732e2f3ec2bea83d19628331349"
-        "2caa9d4aff1c910e9622d2a73f62537f2701aaef6539314043f7bbce5b78c7869aeb2181a67e49eeed2161daf3f881bd"
-        "88592d767f67c4717489119226c2f011d4cab803e9d71650a6f80698e2f8491d12191a04406fbc8fbd5f48925f98630e"
-        "68bfb24c0bcb9b55df57510";
-    F12 pw[16];
-    pw[0] = f12_one();
-    for (int i = 1; i < 16; ++i) pw[i] = pw[i - 1] * x;
-    F12 acc = f12_one();
-    for (const char* c = kExp; *c; ++c) {
-        int v = *c <= '9' ? *c - '0' : *c - 'a' + 10;
-        acc = f12_sqr(f12_sqr(f12_sqr(f12_sqr(acc))));
-        if (v) acc = acc * pw[v];
+// x -> x^|z| for the BLS parameter |z| = 0xd201000000010000 on the cyclotomic subgroup
+inline F12 f12_cyclotomic_exp_z(const F12& a) {
+    const uint64_t z = 0xd201000000010000ULL;
+    F12 acc = a;
+    for (int i = 62; i >= 0; --i) {
+        acc = f12_cyclotomic_sqr(acc);
+        if ((z >> i) & 1) acc = acc * a;
     }
     return acc;
 }
+// x^(3 (p^12 - 1) / r).  The factor 3 does not change whether the result is 1 (the result lies in the subgroup of
+// order r, and gcd(3, r) = 1).  Easy part (p^6 - 1)(p^2 + 1); hard part by
+//        3 (p^4 - p^2 + 1) / r = (z - 1)^2 (z + p) (z^2 + p^2 - 1) + 3,   z = -|z|,
+// i.e. five exponentiations by |z| (63 cyclotomic squarings each), conjugations (= inverses) and Frobenius maps.
+inline F12 f12_final_exp(const F12& x) {
+    F12 a = f12_conj(x) * f12_inv(x);            // x^(p^6 - 1)
+    a = f12_frobenius(f12_frobenius(a)) * a;     // ^(p^2 + 1): now in the cyclotomic subgroup
+    auto exp_z = [](const F12& v) { return f12_conj(f12_cyclotomic_exp_z(v)); };  // v^z, z negative
+    const F12 A = exp_z(a) * f12_conj(a);                                   // a^(z - 1)
+    const F12 B = exp_z(A) * f12_conj(A);                                   // a^((z - 1)^2)
+    const F12 C = exp_z(B) * f12_frobenius(B);                              // ^(z + p)
+    const F12 D = exp_z(exp_z(C)) * f12_frobenius(f12_frobenius(C)) * f12_conj(C);  // ^(z^2 + p^2 - 1)
+    return D * f12_cyclotomic_sqr(a) * a;                                   // * a^3
+}
 
-// k * P for a canonical little-endian 256-bit scalar (4 x u64)
+// k * P for a canonical little-endian 256-bit scalar (4 x u64), 4-bit fixed windows
 inline P1 p1_mul(const P1& p, const uint64_t k[4]) {
+    P1 tab[16];
+    tab[0] = p1_inf();
+    tab[1] = p;
+    for (int i = 2; i < 16; ++i) tab[i] = (i & 1) ? p1_add(tab[i - 1], p) : p1_double(tab[i / 2]);
     P1 acc = p1_inf();
-    for (int i = 255; i >= 0; --i) {
-        acc = p1_double(acc);
-        if ((k[i >> 6] >> (i & 63)) & 1) acc = p1_add(acc, p);
+    for (int i = 63; i >= 0; --i) {
+        acc = p1_double(p1_double(p1_double(p1_double(acc))));
+        const unsigned d = (unsigned)(k[i >> 4] >> (4 * (i & 15))) & 15u;
+        if (d) acc = p1_add(acc, tab[d]);
     }
     return acc;
 }
@@ -289,9 +418,11 @@ inline int verify_proof(const uint64_t* commitment, const uint64_t* proof, const
     if (!g2_on_curve(sg2)) return -1;
     // rhs = [z]proof + commitment - [y]G1
     P1 rhs = p1_add(p1_add(p1_mul(Pi, z), C), p1_neg(p1_mul(p1_generator(), y)));
-    bool ok1 = true, ok2 = true;
-    F12 f = miller_loop(sg2, Pi, ok1) * miller_loop(g2_generator(), p1_neg(rhs), ok2);
-    if (!ok1 || !ok2) return 0;
+    const G2Affine qs[2] = {sg2, g2_generator()};
+    const P1 ps[2] = {Pi, p1_neg(rhs)};
+    bool ok = true;
+    const F12 f = multi_miller_loop(qs, ps, 2, ok);
+    if (!ok) return 0;
     return f12_is_one(f12_final_exp(f)) ? 1 : 0;
 }
 
