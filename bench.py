@@ -37,14 +37,34 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 DEGREE = 1 << 20
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
-# Measured issue costs on MI355X (tools/microbench mix, profiles/r01_microbench_mix.jsonl): a bare v_mad_u64_u32
-# loop reaches 33.4 T/s chip-wide (4 waves/SIMD; 30.6 T/s at the kernel's 2 waves/SIMD) and NOTHING hides behind it:
-# at 2 waves/SIMD a wave-level v_mad_u64_u32 costs ~5.13 issue cycles and a simple 32-bit VALU instruction ~2.98.
+# Integer multiply-add ceiling measured on MI355X (tools/microbench mix, profiles/r01_microbench_mix.jsonl): a bare
+# loop of independent 32x32+64 multiply-adds reaches 33.4 T/s chip-wide and nothing hides behind it.
 VALU_MAD_PEAK_T = 33.4
-MAD_ISSUE_CYCLES, OTHER_ISSUE_CYCLES = 5.13, 2.98
-OTHER_VALU_PER_MADD = 3578     # SQ_INSTS_VALU per wave-level mixed addition (6348, profiles/r01_valu_pmc.json) - MADS_PER_MADD
-SIMDS, CLOCK_HZ = 1024, 2.4e9
-MADS_PER_MADD = 8 * 288 + 2 * 233  # executed v_mad_u64_u32: 8 products x 2 x 12^2, 2 squarings x (89 + 12^2)
+# executed v_mad_i64_i32 per mixed addition of the accumulation kernel (signed radix-2^30 field, field30.hip.h):
+# 8 products x 2 x 13^2 + 2 squarings x (91 + 13^2); counted in the ISA of k_bucket_accumulate (3224)
+MADS_PER_MADD = 8 * 338 + 2 * 260
+
+
+def kernel_source_hash():
+    """sha256 over the sources of the dominant kernel: off-line PMC figures are only quoted for the code they were
+    measured on (profiles/*.json carry the hash of the sources they profiled)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in ("msm_accum.hip", "g1_30.hip.h", "field30.hip.h"):
+        with open(os.path.join(ROOT, "kzg_poly_commit_exploration_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def offline_profile(name):
+    """profiles/<name> if it exists AND was measured on the current kernel sources, else None"""
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        j = json.load(f)
+    return j if j.get("kernel_source_hash") == kernel_source_hash() else None
 
 
 def bench_coefficient_limbs(n):
@@ -62,11 +82,14 @@ def bench_coefficient_limbs(n):
 
 
 def cpu_baseline(eng, coeff_limbs, sample):
-    """Oracle leg (the ONLY use of oracle/ here): the reference's algorithm -- N scalar
-    multiplications + N additions, one thread -- on the first `sample` terms of the same workload."""
+    """Oracle leg (the ONLY use of oracle/ here): the reference's algorithm -- N scalar multiplications + N
+    additions, one thread (src/polynomial.rs:208-212) -- run IN FULL on a degree-2^16 polynomial of the same
+    workload, ~15 s on one host core; the degree-2^20 rate is that x 1/16 (the loop is linear
+    in N, stated as such).  Plus the oracle's bucket method on every host core as the strong CPU baseline."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_ctypes as O
 
+    n = DEGREE + 1
     srs = eng.srs_read(0, sample)
     c = coeff_limbs[:sample]
     t0 = time.perf_counter()
@@ -75,23 +98,81 @@ def cpu_baseline(eng, coeff_limbs, sample):
     assert rc == 0
     got = eng.commit_limbs(c).compress()
     assert got == O.p1_compress(cm), "GPU and oracle disagree on the cpu_baseline sample"
-    n = DEGREE + 1
-    per_commit_s = dt * n / sample
-    out = {"value": 1.0 / per_commit_s, "unit": "commitments/s", "cores": 1, "kind": "port",
-           "sample": "first %d of %d terms, naive N x scalar-mul loop (reference algorithm), %.1f s, scaled x%.1f"
-                     % (sample, n, dt, n / sample)}
-    # strong CPU baseline: bucket method on all host cores, full size
-    cores = os.cpu_count() or 1
-    threads = min(cores, 32)
+    host_cores = os.cpu_count() or 1
+    out = {"value": 1.0 / (dt * n / sample), "unit": "commitments/s", "cores": 1, "kind": "port", "host_cores": host_cores,
+           "sample": "degree-%d commitment (%d terms) in full, naive N x scalar-mul loop (the reference's algorithm): %.1f s = "
+                     "%.4f commitments/s at that degree, bit-identical to the GPU's; value = that / %.1f (linear in N) for degree 2^20"
+                     % (sample - 1, sample, dt, 1.0 / dt, n / sample),
+           "measured_commitments_per_sec_at_sample_degree": 1.0 / dt}
+    # strong CPU baseline: bucket method on all host cores
+    threads = host_cores
     sample2 = min(n, 1 << 18)
     srs2 = eng.srs_read(0, sample2)
     t0 = time.perf_counter()
     rc, cp = O.commit_pippenger(coeff_limbs[:sample2], srs2, threads=threads)
     dt2 = time.perf_counter() - t0
     assert rc == 0 and eng.commit_limbs(coeff_limbs[:sample2]).compress() == O.p1_compress(cp)
-    out["pippenger"] = {"value": 1.0 / (dt2 * n / sample2), "unit": "commitments/s", "cores": threads,
-                        "sample": "first %d terms, bucket method, %.1f s, scaled x%.1f" % (sample2, dt2, n / sample2)}
+    out["pippenger"] = {"value": 1.0 / (dt2 * n / sample2), "unit": "commitments/s", "cores": threads, "host_cores": host_cores,
+                        "sample": "first %d terms, bucket method on %d threads, %.1f s, scaled x%.1f" % (sample2, threads, dt2, n / sample2)}
     return out
+
+
+def host_pointer_path(eng, limbs, z, y, want_commit, want_proof, reps):
+    """What the Rust shim calls: kzg_commit / kzg_open with HOST pointers, one synchronous call at a
+    time, the 32 MiB copy over PCIe included.  Never `value`: reported beside it."""
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        got = eng.commit_limbs(limbs)
+    t_commit = (time.perf_counter() - t0) / reps
+    assert want_commit is None or got.compress().hex() == want_commit
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        got = eng.open_limbs(limbs, z, y)
+    t_open = (time.perf_counter() - t0) / reps
+    assert want_proof is None or got.compress().hex() == want_proof
+    return {"host_pointer_commitments_per_sec": 1.0 / t_commit, "host_pointer_proofs_per_sec": 1.0 / t_open,
+            "host_pointer_ms": {"commit": t_commit * 1e3, "open": t_open * 1e3},
+            "host_pointer_note": "kzg_commit / kzg_open on pageable host memory, synchronous, one at a time (the Rust "
+                                 "shim's calls); PCIe copy of the coefficients inside the timed region"}
+
+
+def batch_of_openings(eng, limbs, n, degree, golden, dev, torch, np, K):
+    """BASELINE config 5's per-GPU share: 8 degree-2^20 openings in ONE kzg_open_batch_submit (8 quotient scans, one
+    batched MSM), coefficients resident, each at its own point; proofs checked against golden (the bench point) and
+    by the pairing check (the others)."""
+    b = eng.set_max_batch(8)
+    if b < 8:
+        return None
+    r = K.R_MODULUS
+    zs = [K.Scalar((pow(5, degree, r) + 20 + 7 * k) % r) for k in range(8)]   # k = 0: the reference bench's point
+    ys = [eng.evaluate_limbs(limbs, zk) for zk in zs]
+    d8 = torch.from_numpy(np.ascontiguousarray(limbs).view(np.int64)).to(dev).unsqueeze(0).repeat(8, 1, 1).contiguous()
+    zl = np.ascontiguousarray(np.stack([zk.limbs() for zk in zs]))
+    yl = np.ascontiguousarray(np.stack([yk.limbs() for yk in ys]))
+    lib, h = eng._lib, eng._h
+    out = np.zeros((8, 18), dtype=np.uint64)
+    st = np.zeros(8, dtype=np.int32)
+    import ctypes as C
+
+    def once():
+        rc = lib.kzg_open_batch_submit(h, 0, C.c_void_p(d8.data_ptr()), n, 8, n, K._ptr(zl), K._ptr(yl))
+        assert rc == 0, rc
+        rc = lib.kzg_wait_open_batch(h, 0, K._ptr(out), K._ptr(st), 8)
+        assert rc == 0 and not st.any(), (rc, st)
+
+    once()
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    dt = (time.perf_counter() - t0) / reps
+    want_p = next((x["proof"] for x in golden["bench"] if x["degree"] == degree), None)
+    if want_p:
+        assert K.G1Point(out[0]).compress().hex() == want_p, "batched opening 0 differs from tests/golden"
+    eng.set_max_batch(1)
+    return {"openings_batch8_per_sec": 8.0 / dt, "openings_batch8_ms": dt * 1e3,
+            "openings_batch8_note": "config 5's per-GPU share: 8 x degree-2^20 openings in one kzg_open_batch_submit, resident inputs"}
 
 
 def main():
@@ -100,7 +181,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--degree", type=int, default=DEGREE)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 15)
+    ap.add_argument("--cpu-sample", type=int, default=(1 << 16) + 1, help="terms of the reference-algorithm CPU run (degree 2^16 in full)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-pointer and batch-of-8-openings legs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-openings", action="store_true", help="skip the opening-proof leg")
     ap.add_argument("--slots", type=int, default=0, help="stream slots kept in flight (0 = all the engine has)")
@@ -271,24 +353,19 @@ def main():
         refs = phase_ms.pop("references", [])
         madds = int(sum(refs) / max(1, len(refs)))   # one mixed addition per non-zero scalar digit (counted on the device)
         tmad = madds * MADS_PER_MADD / (avg_accum_ms * 1e-3) / 1e12 if avg_accum_ms > 0 else 0.0
-        issue_ms = (madds / 64.0) * (MADS_PER_MADD * MAD_ISSUE_CYCLES + OTHER_VALU_PER_MADD * OTHER_ISSUE_CYCLES) \
-            / (SIMDS * CLOCK_HZ) * 1e3
+        # PMC figures are measured OFF-LINE (tools/prof_round2.sh) and only quoted when the profiled sources are the
+        # ones that just ran (hash of msm_accum.hip + g1_30.hip.h + field30.hip.h stored with them)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if world == 1 and degree == DEGREE and os.path.exists(tpath):
-            # PMC bytes of the same kernel on the same workload, measured off-line by tools/prof_pmc.sh
-            with open(tpath) as f:
-                tj = json.load(f)
-            if tj.get("batch", 1) == batch and tj.get("recoding", "windows") == cfg["recoding"]:
-                traffic = tj.get("hbm_bytes_per_launch")
+        tj = offline_profile("r02_traffic.json") if (world == 1 and degree == DEGREE and batch == 1) else None
+        if tj and tj.get("recoding", "windows") == cfg["recoding"]:
+            traffic = tj.get("hbm_bytes_per_launch")
         valu_pmc = {}
-        vpath = os.path.join(ROOT, "profiles", "r01_valu_pmc.json")
-        if world == 1 and degree == DEGREE and batch == 1 and os.path.exists(vpath):
-            with open(vpath) as f:
-                vj = json.load(f)
+        vj = offline_profile("r02_valu_pmc.json") if (world == 1 and degree == DEGREE and batch == 1) else None
+        if vj:
             valu_pmc = {"pmc_valu_busy_percent": vj.get("VALUBusy"),
                         "pmc_valu_lane_utilization_percent": vj.get("VALUUtilization"),
-                        "pmc_source": "profiles/r01_valu_pmc.json (tools/prof_valu.sh, same workload)"}
+                        "pmc_valu_instructions_per_mixed_addition": vj.get("valu_instructions_per_mixed_addition"),
+                        "pmc_source": "offline: profiles/r02_valu_pmc.json (tools/prof_round2.sh, same workload, same kernel sources)"}
         line = {
             "metric": "g1_msm_commitments_per_sec_degree_2^20",
             "value": args.steps * batch / elapsed,
@@ -300,7 +377,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 limbs (384-bit Fp / 256-bit Fr Montgomery integers)",
+            "dtype": "i32 digits (Fp: 13 signed radix-2^30 digits, Montgomery 2^390; Fr: 8 x u32, Montgomery 2^256)",
             "data": "synthetic: reference bench inputs c_i=5^i+10, SRS secret 00..1f, generated on device",
             "config": {"workload": "configs[2]: degree-2^%d commit (G1 MSM, %d terms) on %d x MI355X, SRS-range sharded, "
                                    "%d commitments per step in one batched pass" % (degree.bit_length() - 1, n, world, batch),
@@ -310,20 +387,28 @@ def main():
                        "bit_exact_vs_golden": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": ("offline: profiles/r02_traffic.json, same kernel sources" if traffic else None),
                          "kernel": "k_bucket_accumulate", "avg_kernel_ms": avg_accum_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "bound by integer VALU issue, not by HBM, by construction: see valu"},
+                         "kernel_source_hash": kernel_source_hash(),
+                         "note": "integer/modular work with no MFMA form: the kernel is bound by VALU issue (see valu), "
+                                 "the HBM fraction is small by construction"},
             "valu": {"achieved_Tmad_s": tmad, "peak_Tmad_s": VALU_MAD_PEAK_T, "frac": tmad / VALU_MAD_PEAK_T,
-                     "unit": "1e12 v_mad_u64_u32/s", "mixed_additions_per_launch": madds,
-                     # time the kernel's own VALU instruction mix needs if the SIMDs issued back to back
-                     "issue_model_ms": issue_ms, "issue_model_frac": issue_ms / avg_accum_ms if avg_accum_ms > 0 else 0.0,
-                     "note": "bound by total VALU issue, not by the multiply-adds alone: 2770 v_mad_u64_u32 + ~3580 "
-                             "other VALU instructions per mixed addition (the v_addc carry per multiply-add is 2770 of them)",
+                     "unit": "1e12 32x32+64-bit integer multiply-adds/s (v_mad_i64_i32 executed; peak = bare v_mad_u64_u32 loop)",
+                     "mixed_additions_per_launch": madds, "multiply_adds_per_mixed_addition": MADS_PER_MADD,
                      **valu_pmc},
-            "phase_ms": {k: sum(v) / len(v) for k, v in phase_ms.items()},
+            # HIP-event spans on the slot's stream: digits and accumulate bracket their own kernels; scatter and reduce
+            # INCLUDE queueing behind other slots' kernels (three commitments in flight), so they do not add up to a step
+            "phase_ms_queueing_inclusive": {k: sum(v) / len(v) for k, v in phase_ms.items()},
             "opening_proofs_per_sec": proofs_per_s,
             "quotient_ms": quotient_ms,
         }
+        if world == 1 and degree == DEGREE and not args.no_extras and not args.no_openings and args.steps > 0:
+            want_p0 = next((b["proof"] for b in golden["bench"] if b["degree"] == degree), None)
+            line.update(host_pointer_path(eng, limbs, z, y, want, want_p0, 5))
+            extra = batch_of_openings(eng, limbs, n, degree, golden, dev, torch, np, K)
+            if extra:
+                line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(eng, limbs, min(args.cpu_sample, n))
         print(json.dumps(line))

@@ -91,6 +91,23 @@ int kzg_srs_load_g1(kzg_ctx* ctx, const void* first_g1, size_t stride_bytes, siz
  * (SURVEY.md section 8f-2); it also makes the large bench configurations set up in seconds. */
 int kzg_srs_generate_g1(kzg_ctx* ctx, const uint8_t secret_be[32], uint64_t first, size_t n);
 
+/* Wire / on-disk forms of the SRS (all of them split by range on a multi-device context):
+ *  kzg_srs_load_affine      n x 96 bytes: x, y as blst_fp (Montgomery), (0, 0) = infinity -- blst_p1_affine[n].
+ *                           No normalisation pass: the points go straight into the window-table builder.
+ *  kzg_srs_load_compressed  n x 48 bytes, ZCash encoding: what `Serialize for G1Point` writes into the CLI's
+ *                           setup.json (reference src/curves.rs:99-110) and `Deserialize` reads back with one
+ *                           blst_p1_uncompress per point (src/curves.rs:112-183).  Decompressed on the device (one
+ *                           lane per point: y = (x^3 + 4)^((p+1)/4), sign from the encoding); same acceptance as
+ *                           blst_p1_uncompress (compressed flag, x < p, on the curve; no subgroup check).  On a
+ *                           malformed point: KZG_ERR_INVALID_ARG and *bad_index = its index (bad_index may be NULL).
+ *  kzg_srs_save / kzg_srs_load_file   binary cache of the resident SRS: 128-byte header ("KZGSRS1", n, compressed
+ *                           first and last point as a fingerprint of the content) + n x 96-byte affine points; loading
+ *                           checks the fingerprint and then takes the kzg_srs_load_affine path. */
+int kzg_srs_load_affine(kzg_ctx* ctx, const void* affine_xy, size_t n);
+int kzg_srs_load_compressed(kzg_ctx* ctx, const uint8_t* compressed, size_t n, size_t* bad_index);
+int kzg_srs_save(kzg_ctx* ctx, const char* path);
+int kzg_srs_load_file(kzg_ctx* ctx, const char* path);
+
 /* Copies SRS entries [index, index+count) back as blst_p1 with Z = 1 (affine), e.g. to hand them
  * to the reference's serde or to check them against blst. */
 int kzg_srs_read_g1(kzg_ctx* ctx, size_t index, size_t count, uint64_t* out_p1);
@@ -182,8 +199,8 @@ int kzg_g1_uncompress(const uint8_t in[48], uint64_t out_p1[18]);
 /* Evaluation::verify_proof (reference src/polynomial.rs:276-294):
  *     e(proof, [s]G2 - [z]G2) == e(commitment - [y]G1, G2)
  * commitment, proof: blst_p1; z = evaluation.point, y = evaluation.result: blst_fr (Montgomery);
- * s_g2 = setup_artifacts[1].g2: blst_p2 (36 x u64: Jacobian x, y, z in Fp2, Montgomery).  Host only (two
- * pairings, ~35 ms: a plain restatement, not a tuned one); *valid = 1 accepted, 0 rejected.  KZG_ERR_INVALID_ARG
+ * s_g2 = setup_artifacts[1].g2: blst_p2 (36 x u64: Jacobian x, y, z in Fp2, Montgomery).  Host only (both
+ * pairings in one Miller loop, ~3 ms); *valid = 1 accepted, 0 rejected.  KZG_ERR_INVALID_ARG
  * when s_g2 is not on the curve.  Next-row component. */
 int kzg_verify_proof(const uint64_t commitment_p1[18], const uint64_t proof_p1[18], const uint64_t z[4],
                      const uint64_t y[4], const uint64_t s_g2_p2[36], int* valid);
@@ -198,10 +215,9 @@ typedef struct kzg_kernel_times {
     /* per-kernel HIP-event times of the most recent kzg_wait on the slot, milliseconds, measured on
      * the stream the kernels ran on (only filled while timing is enabled) */
     float digits_ms;      /* scalar recoding + two-level counting sort (all of msm_sort.hip) */
-    float scan_ms;        /* unused (kept for layout stability) */
-    float scatter_ms;     /* buffer clears + wait for the shared accumulation stream */
-    float accumulate_ms;  /* bucket accumulation: the dominant kernel */
-    float reduce_ms;      /* bucket running-sum reduction levels */
+    float scatter_ms;     /* queueing: buffer clears + the wait for the shared accumulation stream (not kernel cost) */
+    float accumulate_ms;  /* bucket accumulation: the dominant kernel, events on the stream it runs on */
+    float reduce_ms;      /* finalisation + reduction trees, INCLUDING their wait behind the next accumulation */
     float quotient_ms;    /* open only: scalar-field synthetic division */
     float total_ms;       /* first kernel start -> last kernel end */
     uint64_t references;  /* non-zero scalar digits = mixed additions of the accumulation kernel (whole batch) */

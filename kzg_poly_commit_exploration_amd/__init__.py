@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "kzg_ctx_create", "kzg_ctx_destroy", "kzg_strerror", "kzg_last_error",
     "kzg_srs_load_g1", "kzg_srs_generate_g1", "kzg_srs_read_g1", "kzg_srs_len",
     "kzg_commit", "kzg_commit_le_bytes", "kzg_open", "kzg_quotient", "kzg_evaluate",
+    "kzg_srs_load_affine", "kzg_srs_load_compressed", "kzg_srs_save", "kzg_srs_load_file",
     "kzg_ctx_create_multi", "kzg_num_devices", "kzg_rccl_exchanges", "kzg_num_slots", "kzg_commit_submit", "kzg_open_submit", "kzg_wait",
     "kzg_set_max_batch", "kzg_max_batch", "kzg_commit_batch_submit", "kzg_wait_batch",
     "kzg_open_batch_submit", "kzg_wait_open_batch", "kzg_g1_uncompress",
@@ -58,7 +59,7 @@ class KzgError(Exception):
 
 class KernelTimes(C.Structure):
     _fields_ = [(n, C.c_float) for n in
-                ("digits_ms", "scan_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "quotient_ms", "total_ms")
+                ("digits_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "quotient_ms", "total_ms")
                 ] + [("references", C.c_uint64)]
 
 
@@ -93,6 +94,10 @@ def load_library():
         "kzg_srs_load_g1": (i, [vp, vp, sz, sz]),
         "kzg_srs_generate_g1": (i, [vp, u8p, C.c_uint64, sz]),
         "kzg_srs_read_g1": (i, [vp, sz, sz, vp]),
+        "kzg_srs_load_affine": (i, [vp, vp, sz]),
+        "kzg_srs_load_compressed": (i, [vp, vp, sz, C.POINTER(sz)]),
+        "kzg_srs_save": (i, [vp, C.c_char_p]),
+        "kzg_srs_load_file": (i, [vp, C.c_char_p]),
         "kzg_srs_len": (sz, [vp]),
         "kzg_commit": (i, [vp, vp, sz, vp]),
         "kzg_commit_le_bytes": (i, [vp, vp, sz, vp]),
@@ -322,6 +327,28 @@ class Engine:
         n = a.shape[0]
         stride = a.strides[0] if stride is None else stride
         _check(self._lib.kzg_srs_load_g1(self._h, _ptr(a), stride, n), self._h)
+
+    def srs_load_affine(self, xy_array):
+        """(n, 12) uint64: x, y as blst_fp (Montgomery); (0, 0) = infinity"""
+        a = np.ascontiguousarray(xy_array, dtype=np.uint64).reshape(-1, 12)
+        _check(self._lib.kzg_srs_load_affine(self._h, _ptr(a), a.shape[0]), self._h)
+
+    def srs_load_compressed(self, data):
+        """n x 48 bytes (ZCash encoding); raises KzgError with .bad_index on a malformed point"""
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        assert buf.size % 48 == 0
+        bad = C.c_size_t(0)
+        rc = self._lib.kzg_srs_load_compressed(self._h, _ptr(buf), buf.size // 48, C.byref(bad))
+        if rc != KZG_OK:
+            e = KzgError(rc, self._lib.kzg_strerror(rc).decode() + ": " + self._lib.kzg_last_error(self._h).decode())
+            e.bad_index = None if bad.value == C.c_size_t(-1).value else int(bad.value)
+            raise e
+
+    def srs_save(self, path):
+        _check(self._lib.kzg_srs_save(self._h, os.fsencode(path)), self._h)
+
+    def srs_load_file(self, path):
+        _check(self._lib.kzg_srs_load_file(self._h, os.fsencode(path)), self._h)
 
     def srs_generate(self, secret_be, n, first=0):
         _check(self._lib.kzg_srs_generate_g1(self._h, bytes(secret_be), first, n), self._h)

@@ -58,6 +58,7 @@ struct Slot {
     uint32_t* d_sorted = nullptr;
     void* d_buckets = nullptr;
     void *d_part_a = nullptr, *d_part_b = nullptr;  // head / tail partials of the accumulation segments
+    void* d_pair_scratch = nullptr;  // prefix products of the affine front end (msm_accum.hip)
     void* d_heavy_ws = nullptr;   // long-bucket registry + tree buffers of msm_finalize.hip
     void* d_arena = nullptr;     // Row[] then Col[] vectors of the bucket matrix
     void* d_final = nullptr;
@@ -144,6 +145,8 @@ struct TmpStream {
 void free_slot_msm(Slot& s) {
     hipFree(s.d_cnt); hipFree(s.d_offs); hipFree(s.d_block_sums); hipFree(s.d_pairs); hipFree(s.d_sorted);
     hipFree(s.d_buckets); hipFree(s.d_part_a); hipFree(s.d_part_b); hipFree(s.d_heavy_ws); hipFree(s.d_arena); hipFree(s.d_final);
+    hipFree(s.d_pair_scratch);
+    s.d_pair_scratch = nullptr;
     if (s.h_final) hipHostFree(s.h_final);
     s.d_cnt = s.d_offs = s.d_block_sums = s.d_sorted = nullptr;
     s.d_pairs = nullptr;
@@ -268,6 +271,7 @@ int setup_slots_impl(kzg_ctx* ctx) {
         HIP_TRY(ctx, hipMalloc(&s.d_buckets, (size_t)cfg.nb * B * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_part_a, (size_t)kMaxAccumLanes * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_part_b, (size_t)kMaxAccumLanes * kXyzzBytes));
+        HIP_TRY(ctx, hipMalloc(&s.d_pair_scratch, accumulate_pair_scratch_bytes(pairs)));
         HIP_TRY(ctx, hipMalloc(&s.d_heavy_ws, heavy_workspace_bytes()));
         HIP_TRY(ctx, hipMalloc(&s.d_arena, ctx->arena_records * B * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_final, ctx->final_records * B * kXyzzBytes));
@@ -350,7 +354,7 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 3], hs));
     launch_bucket_accumulate(hs, ctx->d_table, s.d_sorted, s.d_offs, nbt, lanes, s.d_buckets, s.d_part_a, s.d_part_b,
-                             ctx->accum_lds_bytes);
+                             ctx->accum_lds_bytes, s.d_pair_scratch, (uint64_t)n * cfg.max_digits * batch);
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], hs));
     if (ctx->serialize_accum) {
         HIP_TRY(ctx, hipEventRecord(s.accum_ev, hs));
@@ -452,6 +456,14 @@ __global__ void k_tail_nonzero(const uint32_t* __restrict__ c, uint64_t from, ui
     uint4 a = p[0], b = p[1];
     if (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) atomicOr(flag, 1u);
 }
+
+// HIP multiplexes the streams of a process onto 4 hardware queues by default.  A context uses 4 streams of its own
+// (3 slots + the accumulation stream); as soon as the host application (or RCCL, or torch) has streams too, two of
+// them share a queue and a slot's reduction serialises in front of the next accumulation kernel (1.2 ms bubbles,
+// tools/gaps.py).  The variable is read when the HIP runtime initialises, so it is set when this library is loaded
+// (never overriding the user's own setting); a host that initialises HIP before loading the library has to export
+// GPU_MAX_HW_QUEUES=8 itself.
+__attribute__((constructor)) static void kzg_library_loaded() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 // asynchronous / device-pointer entry points belong to ONE device: refused on a multi-device context
 #define KZG_SINGLE_DEVICE_ONLY(ctx)                                                                        \
@@ -635,6 +647,150 @@ int kzg_srs_generate_g1(kzg_ctx* ctx, const uint8_t secret_be[32], uint64_t firs
     return setup_slots(ctx);
 }
 
+// level 0 is in d_table (builder's form): build the other levels, convert, size the slots
+static int finish_srs_from_level0(kzg_ctx* ctx, hipStream_t st, size_t n) {
+    DevBuf d_prefix, d_xyzz;
+    HIP_TRY(ctx, hipMalloc(&d_prefix.p, n * 48));
+    HIP_TRY(ctx, hipMalloc(&d_xyzz.p, n * kXyzzBytes));
+    ctx->n = n;
+    int rc = build_tables(ctx, st, d_xyzz.p, d_prefix.p);
+    if (rc) {
+        ctx->n = 0;
+        return rc;
+    }
+    return setup_slots(ctx);
+}
+
+int kzg_srs_load_affine(kzg_ctx* ctx, const void* affine_xy, size_t n) {
+    if (!ctx || !affine_xy || !n) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->multi) {
+        ctx->last_error.clear();
+        return multi_srs_load_affine(ctx->multi, affine_xy, n);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = srs_prepare(ctx, n);
+    if (rc) return rc;
+    DevBuf d_in;
+    HIP_TRY(ctx, hipMalloc(&d_in.p, n * 96));
+    TmpStream st;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipMemcpyAsync(d_in.p, affine_xy, n * 96, hipMemcpyHostToDevice, st.s));
+    launch_affine96_to_table(st.s, d_in.p, (uint32_t)n, ctx->d_table);
+    return finish_srs_from_level0(ctx, st.s, n);
+}
+
+int kzg_srs_load_compressed(kzg_ctx* ctx, const uint8_t* compressed, size_t n, size_t* bad_index) {
+    if (!ctx || !compressed || !n) return KZG_ERR_INVALID_ARG;
+    if (bad_index) *bad_index = (size_t)-1;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->multi) {
+        ctx->last_error.clear();
+        return multi_srs_load_compressed(ctx->multi, compressed, n, bad_index);
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = srs_prepare(ctx, n);
+    if (rc) return rc;
+    DevBuf d_in, d_status;
+    HIP_TRY(ctx, hipMalloc(&d_in.p, n * 48));
+    HIP_TRY(ctx, hipMalloc(&d_status.p, 4));
+    TmpStream st;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
+    HIP_TRY(ctx, hipMemcpyAsync(d_in.p, compressed, n * 48, hipMemcpyHostToDevice, st.s));
+    HIP_TRY(ctx, hipMemsetAsync(d_status.p, 0xff, 4, st.s));
+    launch_uncompress(st.s, d_in.p, (uint32_t)n, ctx->d_table, (uint32_t*)d_status.p);
+    uint32_t status = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&status, d_status.p, 4, hipMemcpyDeviceToHost, st.s));
+    HIP_TRY(ctx, hipStreamSynchronize(st.s));
+    if (status != 0xffffffffu) {  // a malformed point (not compressed form, x >= p, not on the curve): as blst_p1_uncompress
+        if (bad_index) *bad_index = status - 1;
+        ctx->last_error = "compressed point " + std::to_string(status - 1) + " is malformed";
+        hipFree(ctx->d_table);
+        ctx->d_table = nullptr;
+        return KZG_ERR_INVALID_ARG;
+    }
+    return finish_srs_from_level0(ctx, st.s, n);
+}
+
+// ---- binary SRS cache: 128-byte header + n x 96-byte affine points ----------------------------------------------
+namespace {
+struct SrsFileHeader {
+    char magic[8];        // "KZGSRS1"
+    uint64_t n;
+    uint8_t first[48];    // compressed encodings of the first and the last point: fingerprint of the content
+    uint8_t last[48];
+    uint8_t reserved[16];
+};
+static_assert(sizeof(SrsFileHeader) == 128, "header layout");
+const char kSrsMagic[8] = {'K', 'Z', 'G', 'S', 'R', 'S', '1', 0};
+
+void affine96_compress(const uint64_t* xy, uint8_t out[48]) {
+    hf::P1 p;
+    std::memcpy(&p.x, xy, 48);
+    std::memcpy(&p.y, xy + 6, 48);
+    bool inf = true;
+    for (int i = 0; i < 12; i++) inf = inf && xy[i] == 0;
+    std::memset(&p.z, 0, 48);
+    if (!inf) p.z = hf::kOne;
+    hf::p1_compress(out, p);
+}
+}  // namespace
+
+int kzg_srs_save(kzg_ctx* ctx, const char* path) {
+    if (!ctx || !path) return KZG_ERR_INVALID_ARG;
+    const size_t n = kzg_srs_len(ctx);
+    if (!n) return KZG_ERR_NO_SRS;
+    FILE* f = std::fopen(path, "wb");
+    if (!f) return KZG_ERR_INVALID_ARG;
+    SrsFileHeader h;
+    std::memset(&h, 0, sizeof h);
+    std::memcpy(h.magic, kSrsMagic, 8);
+    h.n = n;
+    bool ok = std::fwrite(&h, sizeof h, 1, f) == 1;
+    const size_t chunk = 1 << 16;
+    std::vector<uint64_t> p1(chunk * 18), xy(chunk * 12);
+    for (size_t at = 0; at < n && ok; at += chunk) {
+        const size_t take = n - at < chunk ? n - at : chunk;
+        int rc = kzg_srs_read_g1(ctx, at, take, p1.data());
+        if (rc != KZG_OK) {
+            std::fclose(f);
+            return rc;
+        }
+        for (size_t i = 0; i < take; i++) std::memcpy(&xy[12 * i], &p1[18 * i], 96);  // x, y of the affine blst_p1; infinity reads (0, 0)
+        if (at == 0) affine96_compress(xy.data(), h.first);
+        if (at + take == n) affine96_compress(&xy[12 * (take - 1)], h.last);
+        ok = std::fwrite(xy.data(), 96, take, f) == take;
+    }
+    ok = ok && std::fseek(f, 0, SEEK_SET) == 0 && std::fwrite(&h, sizeof h, 1, f) == 1;
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? KZG_OK : KZG_ERR_INVALID_ARG;
+}
+
+int kzg_srs_load_file(kzg_ctx* ctx, const char* path) {
+    if (!ctx || !path) return KZG_ERR_INVALID_ARG;
+    FILE* f = std::fopen(path, "rb");
+    if (!f) return KZG_ERR_INVALID_ARG;
+    SrsFileHeader h;
+    bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, kSrsMagic, 8) == 0 && h.n > 0 && h.n <= 0x7fffffffu / 32;
+    std::vector<uint64_t> xy;
+    if (ok) {
+        xy.resize((size_t)h.n * 12);
+        ok = std::fread(xy.data(), 96, h.n, f) == h.n;
+    }
+    std::fclose(f);
+    if (ok) {  // fingerprint: first and last point as the header recorded them
+        uint8_t a[48], b[48];
+        affine96_compress(xy.data(), a);
+        affine96_compress(&xy[12 * ((size_t)h.n - 1)], b);
+        ok = std::memcmp(a, h.first, 48) == 0 && std::memcmp(b, h.last, 48) == 0;
+    }
+    if (!ok) {
+        ctx->last_error = "not a KZGSRS1 file, truncated, or its fingerprint does not match its content";
+        return KZG_ERR_INVALID_ARG;
+    }
+    return kzg_srs_load_affine(ctx, xy.data(), (size_t)h.n);
+}
+
 int kzg_srs_read_g1(kzg_ctx* ctx, size_t index, size_t count, uint64_t* out_p1) {
     if (!ctx || !out_p1) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -767,7 +923,6 @@ static int wait_locked(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
     if (s.timing && kind != SLOT_TRIVIAL) {
         float ms = 0;
         hipEventElapsedTime(&ms, s.ev[0], s.ev[1]); s.times.digits_ms = ms;
-        hipEventElapsedTime(&ms, s.ev[1], s.ev[2]); s.times.scan_ms = ms;
         hipEventElapsedTime(&ms, s.ev[2], s.ev[3]); s.times.scatter_ms = ms;
         hipEventElapsedTime(&ms, s.ev[3], s.ev[4]); s.times.accumulate_ms = ms;
         hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;

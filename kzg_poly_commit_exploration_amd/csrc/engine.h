@@ -72,9 +72,13 @@ constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on accumulate_lanes()
 // lanes (= segments) for at most max_refs references; a multiple of the workgroup size
 // alone: no other job is in flight on the context (the light kernels of other slots need no room)
 uint32_t accumulate_lanes(uint64_t max_refs, bool alone = false);
+// d_pair_scratch: accumulate_pair_scratch_bytes(max_refs) of scratch for the affine front end (prefix products of the
+// shared inversions), or null to run plain mixed additions; max_refs bounds the references of this launch
+size_t accumulate_pair_scratch_bytes(uint64_t max_refs);
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
                               uint32_t nb, uint32_t lanes, void* d_buckets /* pre-zeroed */,
-                              void* d_part_a, void* d_part_b, uint32_t lds_reserve_bytes);
+                              void* d_part_a, void* d_part_b, uint32_t lds_reserve_bytes, void* d_pair_scratch,
+                              uint64_t max_refs);
 // adds the head / tail partials of buckets that span several segments (serial for short runs, three passes of
 // 64-wide trees for long ones); d_heavy_ws: heavy_workspace_bytes() of scratch whose first 32 bytes (the
 // counters) the caller has zeroed -- ahead of time, so that nothing sits between the end of the accumulation
@@ -107,6 +111,13 @@ void launch_table_window(hipStream_t s, const void* d_prev_affine, uint32_t n, u
 void launch_srs_generate(hipStream_t s, const uint32_t* secret_raw8 /* 256-bit LE integer */, uint64_t first, uint32_t n,
                          void* d_gtable, void* d_xyzz_tmp, void* d_prefix_tmp, void* d_affine_out);
 size_t srs_gtable_bytes();
+// ---- srs_io.hip ------------------------------------------------------------------------
+// n x 96-byte affine points (x, y as blst_fp; (0, 0) = infinity) -> table level 0 (builder's form)
+void launch_affine96_to_table(hipStream_t s, const void* d_affine96, uint32_t n, void* d_table);
+// n x 48-byte compressed points (ZCash encoding) -> table level 0; *d_status (pre-set to 0xffffffff) receives
+// index + 1 of the first malformed point
+void launch_uncompress(hipStream_t s, const void* d_compressed, uint32_t n, void* d_table, uint32_t* d_status);
+
 // ---- msm_accum.hip (table format) ---------------------------------------------------------
 // rewrites `records` finished table records in place from the builder's 12 x u32 form into the accumulation kernel's
 // native form (13 signed radix-2^30 digits per coordinate, x in words 0..12, y in words 16..28 of the 128-B record)
@@ -129,6 +140,8 @@ kzg_ctx* multi_kid(MultiState* m, int g);
 const char* multi_last_error(const MultiState* m);
 int multi_srs_generate(MultiState* m, const uint8_t secret_be[32], uint64_t first, size_t n);
 int multi_srs_load(MultiState* m, const void* first_g1, size_t stride, size_t n);
+int multi_srs_load_affine(MultiState* m, const void* affine_xy, size_t n);
+int multi_srs_load_compressed(MultiState* m, const uint8_t* compressed, size_t n, size_t* bad_index);
 int multi_srs_read(MultiState* m, size_t index, size_t count, uint64_t* out_p1);
 int multi_commit(MultiState* m, const void* scalars, int is_mont, size_t n, uint64_t out_p1[18]);
 int multi_open(MultiState* m, const uint64_t* coeffs, size_t n, const uint64_t z[4], const uint64_t y[4], uint64_t out_p1[18]);

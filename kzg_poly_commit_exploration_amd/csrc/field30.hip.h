@@ -204,7 +204,12 @@ KZG_HD Fq fq_sqr(const Fq& a) {
 
 // v == 0 (mod p) for |v| < 3.5 p.  The integer is k*p with |k| <= 3; its residue mod 2^30 only depends on digit 0,
 // so seven compares on one word reject everything but ~2^-27 of the non-zero values; the exact test runs then.
-KZG_HD bool fq_is_zero_slow(const Fq& a) {
+#if defined(__HIPCC__)
+static __host__ __device__ __noinline__ bool fq_is_zero_slow(const Fq& a_in) {
+    const Fq a = a_in;
+#else
+inline bool fq_is_zero_slow(const Fq& a) {
+#endif
     const Fq c = fq_canon_digits(a);
     // k*p in canonical balanced digits, k = -3..3
     for (int k = -3; k <= 3; k++) {

@@ -15,7 +15,8 @@ namespace kzg {
 
 // scheduling barrier between the products of the group law: the compiler otherwise interleaves the ten
 // independent-looking multiplications and the live ranges of their operands push the kernel over 2 waves/SIMD
-#if defined(__HIP_DEVICE_COMPILE__)
+// (KZG_G1_30_NO_SB: latency-bound kernels -- one wave per SIMD, 512 registers to spend -- want the opposite)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_G1_30_NO_SB)
 #define KZG_SB30() __builtin_amdgcn_sched_barrier(0)
 #else
 #define KZG_SB30() ((void)0)
@@ -166,6 +167,65 @@ KZG_HD void xyzz30_add(XYZZ30& acc, const XYZZ30& b) {
     KZG_SB30();
     acc.Y = fq_norm(fq_sub_raw(fq_mul(R, fq_sub_raw(Q, X3)), YP));
     acc.X = X3;
+}
+
+// ---- affine pair additions with a shared inversion (the accumulation kernel's front end) ----------------------------
+// Two table points that fall into the same bucket are first added in AFFINE coordinates: lambda = num / den,
+// x3 = lambda^2 - xa - xb, y3 = lambda (xa - x3) - ya -- 2M + 1S once 1/den is known, and the sum enters the bucket's
+// XYZZ accumulator with ONE mixed addition instead of two.  The denominators of all the pairs of a lane are inverted
+// together (Montgomery's trick: 3 products per pair + one safegcd inversion per lane, field30_inv.hip.h).
+// pair_kind: what the forward pass found; the denominator it contributes to the shared product.
+enum : uint32_t {
+    kPairNone = 0,    // no pair in this slot (references in different buckets / end of the segment): denominator 1
+    kPairAdd = 1,     // distinct x: den = xb - xa
+    kPairDouble = 2,  // same point twice: den = 2 ya, num = 3 xa^2
+    kPairCancel = 3,  // opposite points, or both at infinity: the pair contributes nothing
+    kPairOnlyA = 4,   // b at infinity
+    kPairOnlyB = 5    // a at infinity
+};
+KZG_HD bool affine30_is_inf(const Affine30& p) { return fq_all_zero(p.x) && fq_all_zero(p.y); }
+// full decision with both points at hand (signs applied to y): returns the kind and the denominator
+KZG_HD uint32_t pair_classify(const Affine30& a, bool nega, const Affine30& b, bool negb, Fq& den) {
+    const bool ainf = affine30_is_inf(a), binf = affine30_is_inf(b);
+    den = fq_one();
+    if (ainf && binf) return kPairCancel;
+    if (ainf) return kPairOnlyB;
+    if (binf) return kPairOnlyA;
+    const Fq dx = fq_norm(fq_sub_raw(b.x, a.x));
+    if (!fq_is_zero(dx)) {
+        den = dx;
+        return kPairAdd;
+    }
+    const Fq s = fq_norm(fq_add_raw(fq_cneg(a.y, nega), fq_cneg(b.y, negb)));  // ya + yb: 2 ya or 0
+    if (fq_is_zero(s)) return kPairCancel;
+    den = s;
+    return kPairDouble;
+}
+// the sum, given 1/den; kind is kPairAdd or kPairDouble.  MUL / SQR: the field product to use (the accumulation
+// kernel passes real calls here: its loop body must stay inside the instruction cache)
+template <class MulF, class SqrF>
+KZG_HD Affine30 pair_sum_with(uint32_t kind, const Affine30& a, bool nega, const Affine30& b, bool negb, const Fq& inv_den,
+                              MulF mul, SqrF sqr) {
+    const Fq ya = fq_cneg(a.y, nega);
+    Fq num;
+    if (kind == kPairDouble) {
+        const Fq xx = sqr(a.x);
+        num = fq_norm(fq_add_raw(fq_add_raw(xx, xx), xx));
+    } else {
+        num = fq_norm(fq_sub_raw(fq_cneg(b.y, negb), ya));
+    }
+    KZG_SB30();
+    const Fq lambda = mul(num, inv_den);
+    KZG_SB30();
+    Affine30 r;
+    r.x = fq_norm(fq_sub_raw(fq_sub_raw(sqr(lambda), a.x), kind == kPairDouble ? a.x : b.x));
+    KZG_SB30();
+    r.y = fq_norm(fq_sub_raw(mul(lambda, fq_sub_raw(a.x, r.x)), ya));
+    return r;
+}
+KZG_HD Affine30 pair_sum(uint32_t kind, const Affine30& a, bool nega, const Affine30& b, bool negb, const Fq& inv_den) {
+    return pair_sum_with(kind, a, nega, b, negb, inv_den, [](const Fq& x, const Fq& y) { return fq_mul(x, y); },
+                         [](const Fq& x) { return fq_sqr(x); });
 }
 
 // The general addition as ONE real call with its operands in private memory: the latency-bound finalisation and

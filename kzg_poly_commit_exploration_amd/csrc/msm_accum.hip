@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "engine.h"
+#include "field30_inv.hip.h"
 #include "g1_30.hip.h"
 
 namespace kzg {
@@ -146,6 +147,244 @@ __global__ void KZG_ACCUM_ATTR __launch_bounds__(kAccumBlock, 2) k_bucket_accumu
     store_xyzz30(dst, acc);
 }
 
+// ---- the same with an affine front end -----------------------------------------------------------------------------
+// Two consecutive references of a segment that lie in the same bucket are first added in affine coordinates (2M + 1S
+// once the inverse of x2 - x1 is known) and their sum enters the XYZZ accumulator with ONE mixed addition instead of
+// two: per pair 1 (prefix product) + 2 (Montgomery's trick) + 2M + 1S + one mixed addition ~ 15.5 field products
+// instead of 19.4, for one shared inversion per lane (safegcd, ~40 products, field30_inv.hip.h) and a second gather of
+// the two points.
+//   forward pass   pair slot j = references (start + 2j, start + 2j + 1): classify (pair_classify), store the running
+//                  product of the denominators so far and the kind (64-byte record, lane-interleaved: coalesced);
+//   inversion      of the product of all denominators of the lane;
+//   backward pass  slots in descending order: 1/den_j = inv * prefix_j, inv *= den_j; affine sum; mixed addition into
+//                  the accumulator with the run logic of k_bucket_accumulate mirrored (runs flushed when the walk
+//                  crosses the lower end of a bucket).  Slots that are not pairs are walked as single references.
+// Exceptional pairs (equal points, opposite points, infinity) are classified in the forward pass and never poison the
+// shared product: their denominator is 1 (or 2y for a doubling).  Outputs are identical to k_bucket_accumulate's.
+constexpr uint32_t kPairRecU4 = 4;  // prefix record: 13 digits + kind, padded to 64 bytes
+
+// field products of the pair arithmetic as real calls (arguments and result in registers): five inlined products
+// more would push the backward loop past the instruction cache (73 KB measured, 40 % slower than without pairs)
+static __device__ __noinline__ Fq fq_mul_call(Fq a, Fq b) { return fq_mul(a, b); }
+static __device__ __noinline__ Fq fq_sqr_call(Fq a) { return fq_sqr(a); }
+#ifdef KZG_PAIR_CALLS  // A/B switch: the five products of the pair arithmetic as calls or inlined
+#define KZG_PAIR_MUL(a, b) fq_mul_call(a, b)
+#define KZG_PAIR_SQR(a) fq_sqr_call(a)
+#else
+#define KZG_PAIR_MUL(a, b) fq_mul(a, b)
+#define KZG_PAIR_SQR(a) fq_sqr(a)
+#endif
+// the inversion runs once per lane: a real call keeps its ~100 registers of state out of the loops' allocation
+static __device__ __noinline__ void fq_inv_call(Fq* io) {
+    const Fq a = *io;
+    *io = fq_inv(a);
+}
+// rare path of the forward pass (equal / opposite / infinite points): a real call, operands through private memory
+static __device__ __noinline__ uint32_t pair_classify_call(const Affine30* a, bool nega, const Affine30* b, bool negb, Fq* den) {
+    Fq d;
+    const uint32_t kind = pair_classify(*a, nega, *b, negb, d);
+    *den = d;
+    return kind;
+}
+
+__global__ void __launch_bounds__(kAccumBlock, 2) k_bucket_accumulate_pairs(const uint4* __restrict__ table,
+                                                                            const uint32_t* __restrict__ sorted,
+                                                                            const uint32_t* __restrict__ offs, uint32_t nb,
+                                                                            uint32_t lanes, uint4* __restrict__ buckets,
+                                                                            uint4* __restrict__ part_a,
+                                                                            uint4* __restrict__ part_b,
+                                                                            uint4* __restrict__ prefix_buf) {
+    const uint32_t lane = blockIdx.x * kAccumBlock + threadIdx.x;
+    const uint32_t M = offs[nb];
+    const uint32_t L = accumulate_seg_len(M, lanes);
+    const uint64_t start64 = (uint64_t)lane * L;
+    if (start64 >= M) return;
+    const uint32_t start = (uint32_t)start64;
+    const uint32_t end = (M - start < L) ? M : start + L;
+    const uint32_t J = (end - start + 1) / 2;  // pair slots of this lane (the last one may hold a single reference)
+    // record (j, piece) of this lane: ((j * 4 + piece) * lanes + lane): a wave touches 1 KiB contiguous per piece
+    auto rec = [&](uint32_t j, uint32_t piece) { return prefix_buf + ((size_t)(j * kPairRecU4 + piece) * lanes + lane); };
+    // LDS: two point slots per wave (first and second reference of a pair slot), 8 pieces x 64 lanes x 16 B each
+    extern __shared__ uint4 lds_points[];
+    uint4* const slot0 = lds_points + (threadIdx.x >> 6) * (16 * 64);
+    uint4* const slot1 = slot0 + 8 * 64;
+    const uint32_t wl = threadIdx.x & 63;
+    auto dma = [&](uint4* slot, uint32_t r, int first_piece, int pieces) {
+        const char* src = reinterpret_cast<const char*>(table + (size_t)(r & 0x7fffffffu) * kAffineU4);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k >= first_piece && k < first_piece + pieces)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * k),
+                                                 (__attribute__((address_space(3))) void*)(slot + 64 * k), 16, 0, 0);
+    };
+    auto lds_fq = [&](const uint4* slot, int first_piece) {
+        const uint4 a = slot[64 * first_piece + wl], b2 = slot[64 * (first_piece + 1) + wl], c = slot[64 * (first_piece + 2) + wl],
+                    d = slot[64 * (first_piece + 3) + wl];
+        Fq r;
+        r.d[0] = (int32_t)a.x; r.d[1] = (int32_t)a.y; r.d[2] = (int32_t)a.z; r.d[3] = (int32_t)a.w;
+        r.d[4] = (int32_t)b2.x; r.d[5] = (int32_t)b2.y; r.d[6] = (int32_t)b2.z; r.d[7] = (int32_t)b2.w;
+        r.d[8] = (int32_t)c.x; r.d[9] = (int32_t)c.y; r.d[10] = (int32_t)c.z; r.d[11] = (int32_t)c.w;
+        r.d[12] = (int32_t)d.x;
+        return r;
+    };
+
+    // ---------------- forward pass: slot j's x coordinates arrive by LDS-DMA while slot j-1 is multiplied
+    uint32_t b = bucket_of(offs, nb, start);
+    uint32_t b_end = offs[b + 1];
+    Fq run = fq_one();
+    {
+        uint32_t r0 = sorted[start], r1 = start + 1 < end ? sorted[start + 1] : 0u;
+        uint32_t r0n = start + 2 < end ? sorted[start + 2] : 0u, r1n = start + 3 < end ? sorted[start + 3] : 0u;
+        dma(slot0, r0, 0, 4);
+        dma(slot1, r1, 0, 4);
+        for (uint32_t j = 0; j < J; j++) {
+            const uint32_t e0 = start + 2 * j, e1 = e0 + 1;
+            while (b_end <= e0) {
+                b++;
+                b_end = offs[b + 1];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const Fq x0 = lds_fq(slot0, 0), x1 = lds_fq(slot1, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const uint32_t c0 = r0, c1 = r1;
+            if (j + 1 < J) {  // next slot's x coordinates, and the references of the slot after it
+                r0 = r0n;
+                r1 = r1n;
+                dma(slot0, r0, 0, 4);
+                dma(slot1, r1, 0, 4);
+                r0n = e0 + 4 < end ? sorted[e0 + 4] : 0u;
+                r1n = e0 + 5 < end ? sorted[e0 + 5] : 0u;
+            }
+            uint32_t kind = kPairNone;
+            Fq den = fq_one();
+            if (e1 < end && e1 < b_end) {
+                const Fq dx = fq_norm(fq_sub_raw(x1, x0));
+                if (!fq_all_zero(x0) && !fq_all_zero(x1) && !fq_is_zero(dx)) {
+                    kind = kPairAdd;  // the common case needs the x coordinates only
+                    den = dx;
+                } else {
+                    Affine30 a, c;
+                    a.x = x0;
+                    a.y = load_fq(table + (size_t)(c0 & 0x7fffffffu) * kAffineU4 + 4);
+                    c.x = x1;
+                    c.y = load_fq(table + (size_t)(c1 & 0x7fffffffu) * kAffineU4 + 4);
+                    kind = pair_classify_call(&a, (c0 >> 31) != 0, &c, (c1 >> 31) != 0, &den);
+                }
+            }
+            *rec(j, 0) = make_uint4((uint32_t)run.d[0], (uint32_t)run.d[1], (uint32_t)run.d[2], (uint32_t)run.d[3]);
+            *rec(j, 1) = make_uint4((uint32_t)run.d[4], (uint32_t)run.d[5], (uint32_t)run.d[6], (uint32_t)run.d[7]);
+            *rec(j, 2) = make_uint4((uint32_t)run.d[8], (uint32_t)run.d[9], (uint32_t)run.d[10], (uint32_t)run.d[11]);
+            *rec(j, 3) = make_uint4((uint32_t)run.d[12], kind, c0, c1);
+            if (kind == kPairAdd || kind == kPairDouble) run = KZG_PAIR_MUL(run, den);
+        }
+    }
+    // ---------------- one inversion for the lane
+    Fq inv = run;
+    fq_inv_call(&inv);
+
+    // ---------------- backward pass: ONE walk over the references, downwards, one mixed addition per step for
+    // every lane (a pair slot is consumed when the walk reaches its second reference; a slot without a pair is
+    // walked as single references).  Lanes keep their own cursor, so a lane that meets a bucket boundary inside a
+    // slot does not cost its wave an extra addition.  Prefetch: the record of the next step's slot (plain loads) and
+    // the points at the next cursor and below it (LDS-DMA) are requested as soon as this step's kind is known.
+    b = bucket_of(offs, nb, end - 1);
+    uint32_t b_beg = offs[b];
+    b_end = offs[b + 1];
+    XYZZ30 acc = xyzz30_inf();
+    auto flush = [&]() {
+        // the run of bucket b inside [start, end)
+        uint4* dst;
+        if (b_beg >= start && b_end <= end) dst = buckets + (size_t)b * kXyzzU4;  // complete
+        else if (b_beg <= start) dst = part_a + (size_t)lane * kXyzzU4;           // touches the segment start
+        else dst = part_b + (size_t)lane * kXyzzU4;                                // touches only its end
+        store_xyzz30(dst, acc);
+    };
+    auto enter = [&](uint32_t e) {  // make b the bucket of reference e (walking downwards)
+        if (e < b_beg) {
+            flush();
+            acc = xyzz30_inf();
+            do {
+                b--;
+                b_end = b_beg;
+                b_beg = offs[b];
+            } while (b_beg > e);
+        }
+    };
+    uint32_t e = end - 1;                      // cursor: the reference this step starts from
+    // upcoming references below the cursor: w0 = sorted[e], w1 = sorted[e-1], w2 = sorted[e-2], w3 = sorted[e-3]
+    auto ref_at = [&](uint32_t idx_plus_1) { return idx_plus_1 > start ? sorted[idx_plus_1 - 1] : 0u; };
+    uint32_t w0 = sorted[e], w1 = ref_at(e), w2 = e >= 1 ? ref_at(e - 1) : 0u, w3 = e >= 2 ? ref_at(e - 2) : 0u;
+    uint4 q0, q1, q2, q3;
+    {
+        const uint32_t j = (e - start) >> 1;
+        q0 = *rec(j, 0); q1 = *rec(j, 1); q2 = *rec(j, 2); q3 = *rec(j, 3);
+        dma(slot1, w0, 0, 8);  // point at the cursor
+        dma(slot0, w1, 0, 8);  // point below it (used when the step is a pair)
+    }
+    bool more_steps = true;
+    while (more_steps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t j = (e - start) >> 1;
+        const uint32_t kind = q3.y;
+        const bool second = ((e - start) & 1u) != 0;
+        const bool paired = kind != kPairNone && second;  // (a slot of another kind is always entered at its second reference)
+        const uint32_t r_hi = w0, r_lo = w1;              // references at e and e - 1
+        Fq prefix;
+        prefix.d[0] = (int32_t)q0.x; prefix.d[1] = (int32_t)q0.y; prefix.d[2] = (int32_t)q0.z; prefix.d[3] = (int32_t)q0.w;
+        prefix.d[4] = (int32_t)q1.x; prefix.d[5] = (int32_t)q1.y; prefix.d[6] = (int32_t)q1.z; prefix.d[7] = (int32_t)q1.w;
+        prefix.d[8] = (int32_t)q2.x; prefix.d[9] = (int32_t)q2.y; prefix.d[10] = (int32_t)q2.z; prefix.d[11] = (int32_t)q2.w;
+        prefix.d[12] = (int32_t)q3.x;
+        Affine30 pt;  // the point at the cursor
+        pt.x = lds_fq(slot1, 0);
+        pt.y = lds_fq(slot1, 4);
+        Affine30 lo;  // the point below it
+        lo.x = lds_fq(slot0, 0);
+        lo.y = lds_fq(slot0, 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        enter(e);
+        // next step's cursor, its record and its points
+        const uint32_t used = paired ? 2u : 1u;
+        more_steps = e >= start + used;
+        if (more_steps) {
+            e -= used;
+            if (paired) { w0 = w2; w1 = w3; } else { w0 = w1; w1 = w2; w2 = w3; }
+            const uint32_t jn = (e - start) >> 1;
+            q0 = *rec(jn, 0); q1 = *rec(jn, 1); q2 = *rec(jn, 2); q3 = *rec(jn, 3);
+            dma(slot1, w0, 0, 8);
+            dma(slot0, w1, 0, 8);
+            // refill the window: references at e - 2 and e - 3 (those at e and e - 1 are in w0, w1)
+            if (paired) {
+                w2 = e >= start + 2 ? sorted[e - 2] : 0u;
+                w3 = e >= start + 3 ? sorted[e - 3] : 0u;
+            } else {
+                w3 = e >= start + 3 ? sorted[e - 3] : 0u;
+            }
+        }
+        bool neg = (r_hi >> 31) != 0;
+        bool have = true;
+        if (paired) {
+            const bool n0 = (r_lo >> 31) != 0;
+            if (kind == kPairCancel) {
+                have = false;
+            } else if (kind == kPairOnlyA) {
+                pt = lo;
+                neg = n0;
+            } else if (kind != kPairOnlyB) {
+                const Fq den = kind == kPairAdd ? fq_norm(fq_sub_raw(pt.x, lo.x)) : fq_norm(fq_add_raw(fq_cneg(lo.y, n0), fq_cneg(pt.y, neg)));
+                const Fq inv_den = KZG_PAIR_MUL(inv, prefix);
+                KZG_SB30();
+                inv = KZG_PAIR_MUL(inv, den);
+                KZG_SB30();
+                pt = pair_sum_with(kind, lo, n0, pt, neg, inv_den, [](const Fq& x, const Fq& y) { return KZG_PAIR_MUL(x, y); },
+                                   [](const Fq& x) { return KZG_PAIR_SQR(x); });
+                neg = false;
+            }
+        }
+        if (have) xyzz30_madd(acc, pt, neg);
+    }
+    flush();
+}
+
 // ---- table format -------------------------------------------------------------------------------------------------
 // srs_kernels.hip builds the window table with the 12 x u32 field (x | y, 96 B of a 128-B record).  Once it is
 // complete every record is rewritten in place into the accumulation kernel's native form: 13 signed radix-2^30
@@ -208,17 +447,17 @@ void launch_affine_to_p1(hipStream_t s, const void* d_affine, uint32_t n, void* 
 }
 
 uint32_t accumulate_lanes(uint64_t max_refs, bool alone) {
-    // 262144 segments = 1024 workgroups = two full rounds of the 512 that are resident at 256 VGPRs (two workgroups
-    // per CU).  Measured at 2^20 terms with three slots in flight (round 2, signed radix-2^30 field): 262144 lanes
-    // 2.60 ms per launch / 342 commitments/s, 196608 lanes 2.76 ms / 327, 131072 lanes 2.64 ms / 340.  (Round 1's
-    // 206-VGPR kernel left room for the light kernels of the other slots beside it and preferred 196608 lanes in
-    // company; this one fills the register file, so whatever is best alone is best in company too.)
-    // KZG_ACCUM_LANES overrides for experiments.
+    // 131072 segments = 512 workgroups = exactly the one round that is resident at 256 VGPRs (two workgroups per
+    // CU).  Measured at 2^20 terms with three slots in flight (round 2, signed radix-2^30 field), two boxes:
+    // 131072 lanes 2.64 / 2.79 ms per launch and 340 / 333 commitments/s, 196608 lanes 2.76 / 2.82 ms and 327 / 327,
+    // 262144 lanes 2.60 / 2.98 ms and 342 / 321: one resident round is the robust choice.  (Round 1's 206-VGPR kernel
+    // left room for the light kernels of other slots beside it and preferred 196608 lanes; this one fills the
+    // register file.)  KZG_ACCUM_LANES overrides for experiments.
     (void)alone;
     static const uint64_t target = [] {
         const char* v = std::getenv("KZG_ACCUM_LANES");
-        uint64_t l = v ? std::strtoull(v, nullptr, 10) : 262144ull;
-        return l < 64 ? 262144ull : (l > 262144ull ? 262144ull : l);
+        uint64_t l = v ? std::strtoull(v, nullptr, 10) : 131072ull;
+        return l < 64 ? 131072ull : (l > 262144ull ? 262144ull : l);
     }();
     const uint64_t lo = accumulate_min_seg(max_refs);
     uint64_t lanes = (max_refs + lo - 1) / lo;  // segments are at least 8 (tiny jobs: 4) references long
@@ -227,10 +466,35 @@ uint32_t accumulate_lanes(uint64_t max_refs, bool alone) {
     return (uint32_t)lanes;
 }
 
+size_t accumulate_pair_scratch_bytes(uint64_t max_refs) {
+    // one 64-byte record per pair slot: at most max_refs / 2 + one per lane
+    return (size_t)(max_refs / 2 + kMaxAccumLanes) * kPairRecU4 * 16;
+}
+
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
                               uint32_t nb, uint32_t lanes, void* d_buckets, void* d_part_a, void* d_part_b,
-                              uint32_t lds_reserve_bytes) {
+                              uint32_t lds_reserve_bytes, void* d_pair_scratch, uint64_t max_refs) {
     if (!lanes) return;
+    // KZG_ACCUM_PAIRS=1 selects the affine front end (segments of at least 16 references).  Off by default: bit-exact
+    // (the GPU suite runs under it too) but SLOWER on MI355X -- measured at 2^20 terms, same box, 131072 lanes:
+    // 3.66 ms per launch against 2.81 ms for plain mixed additions (3.20 ms without any prefetch, 3.85 ms with a
+    // per-slot loop that let one lane's bucket boundary cost its wave an extra addition, 4.0-4.2 ms with the five pair
+    // products as real calls).  The 3.9 field products a pair saves are eaten by what the product count does not show:
+    // two carry passes and a zero test per affine sum, the prefix records, a second gather, the 64 + 16 LDS-DMA /
+    // LDS reads per step, a loop body of 73 KB against a 64 KB instruction cache, and ~50 products' worth of
+    // strictly serial division steps per lane for the shared inversion.
+    static const int pairs_mode = [] {
+        const char* v = std::getenv("KZG_ACCUM_PAIRS");
+        return v ? std::atoi(v) : 0;
+    }();
+    if (pairs_mode && d_pair_scratch && max_refs / lanes >= 16) {
+        hipLaunchKernelGGL(k_bucket_accumulate_pairs, dim3(lanes / kAccumBlock), dim3(kAccumBlock),
+                           (kAccumBlock / 64) * 16 * 64 * 16 /* two point slots per wave */, s,
+                           reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb, lanes,
+                           reinterpret_cast<uint4*>(d_buckets), reinterpret_cast<uint4*>(d_part_a),
+                           reinterpret_cast<uint4*>(d_part_b), reinterpret_cast<uint4*>(d_pair_scratch));
+        return;
+    }
     // dynamic LDS: the prefetch slots (8 KiB per wave), or more when the caller reserves LDS to shape occupancy
     const uint32_t need = (kAccumBlock / 64) * 8 * 64 * 16;
     if (lds_reserve_bytes < need) lds_reserve_bytes = need;

@@ -176,6 +176,37 @@ int multi_srs_load(MultiState* m, const void* first_g1, size_t stride, size_t n)
     return rc;
 }
 
+int multi_srs_load_affine(MultiState* m, const void* affine_xy, size_t n) {
+    const size_t k = m->kids.size();
+    m->n = 0;
+    for (size_t g = 0; g < k; g++) shard_range(n, g, k, m->lo[g], m->hi[g]);
+    int rc = for_each_kid(m, [&](size_t g) {
+        if (m->hi[g] == m->lo[g]) return (int)KZG_OK;
+        return kzg_srs_load_affine(m->kids[g], (const char*)affine_xy + m->lo[g] * 96, m->hi[g] - m->lo[g]);
+    });
+    if (rc == KZG_OK) m->n = n;
+    return rc;
+}
+
+int multi_srs_load_compressed(MultiState* m, const uint8_t* compressed, size_t n, size_t* bad_index) {
+    const size_t k = m->kids.size();
+    m->n = 0;
+    for (size_t g = 0; g < k; g++) shard_range(n, g, k, m->lo[g], m->hi[g]);
+    std::vector<size_t> bad(k, (size_t)-1);
+    int rc = for_each_kid(m, [&](size_t g) {
+        if (m->hi[g] == m->lo[g]) return (int)KZG_OK;
+        return kzg_srs_load_compressed(m->kids[g], compressed + m->lo[g] * 48, m->hi[g] - m->lo[g], &bad[g]);
+    });
+    if (bad_index)
+        for (size_t g = 0; g < k; g++)
+            if (bad[g] != (size_t)-1) {
+                *bad_index = m->lo[g] + bad[g];
+                break;
+            }
+    if (rc == KZG_OK) m->n = n;
+    return rc;
+}
+
 int multi_srs_read(MultiState* m, size_t index, size_t count, uint64_t* out_p1) {
     if (index > m->n || count > m->n - index) return KZG_ERR_INVALID_ARG;
     for (size_t g = 0; g < m->kids.size() && count; g++) {

@@ -68,6 +68,44 @@ void f30_madd(int32_t* acc, const int32_t* px, const int32_t* py, int neg) {
     memcpy(acc + 39, a.ZZZ.d, 52);
 }
 
+// batched affine pair sums exactly as the accumulation kernel runs them: n pairs (a_i, b_i) with signs, forward pass
+// (classification + prefix products), ONE inversion, backward pass.  out: n x (kind, x3[13], y3[13]).
+void f30_pair_batch(const int32_t* ax, const int32_t* ay, const int32_t* bx, const int32_t* by, const int* nega, const int* negb,
+                    int n, int32_t* out) {
+    Fq* prefix = new Fq[n];
+    uint32_t* kind = new uint32_t[n];
+    Fq run = fq_one();
+    auto pt = [](const int32_t* x, const int32_t* y, int i) {
+        Affine30 p;
+        memcpy(p.x.d, x + 13 * i, 52);
+        memcpy(p.y.d, y + 13 * i, 52);
+        return p;
+    };
+    for (int i = 0; i < n; i++) {
+        Fq den;
+        kind[i] = pair_classify(pt(ax, ay, i), nega[i], pt(bx, by, i), negb[i], den);
+        prefix[i] = run;
+        if (kind[i] == kPairAdd || kind[i] == kPairDouble) run = fq_mul(run, den);
+    }
+    Fq inv = fq_inv(run);
+    for (int i = n - 1; i >= 0; i--) {
+        int32_t* o = out + 27 * i;
+        o[0] = (int32_t)kind[i];
+        memset(o + 1, 0, 26 * 4);
+        if (kind[i] != kPairAdd && kind[i] != kPairDouble) continue;
+        Fq den;
+        const Affine30 a = pt(ax, ay, i), b = pt(bx, by, i);
+        (void)pair_classify(a, nega[i], b, negb[i], den);
+        const Fq inv_den = fq_mul(inv, prefix[i]);
+        inv = fq_mul(inv, den);
+        const Affine30 s = pair_sum(kind[i], a, nega[i], b, negb[i], inv_den);
+        memcpy(o + 1, s.x.d, 52);
+        memcpy(o + 14, s.y.d, 52);
+    }
+    delete[] prefix;
+    delete[] kind;
+}
+
 // the multiplier's column sums in exact arithmetic (__int128): returns the largest |column| / 2^48 seen
 int64_t f30_mul_max_column(const int32_t* a, const int32_t* b) {
     int32_t m[13];

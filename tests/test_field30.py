@@ -236,3 +236,59 @@ def test_group_law_mixed_addition_complete(lib):
         assert (ZZ * rinv) ** 3 % P == (ZZZ * rinv) ** 2 % P
         for val, bound in ((X, 2.6), (Y, 1.4), (ZZ, 0.7), (ZZZ, 0.7)):
             assert abs(val) < bound * P
+
+
+def test_pair_batch_affine_sums_with_shared_inversion(lib):
+    """pair_classify / pair_sum + fq_inv as the accumulation kernel chains them: random pairs of multiples of G with
+    both signs, equal points (doubling), opposite points (cancellation), points at infinity; one inversion for all."""
+    gx = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+    gy = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+    G = (gx, gy)
+    pts = [G]
+    for _ in range(15):
+        pts.append(_ec_add(pts[-1], G))
+    rng = random.Random(37)
+    n = 150
+    cases = []
+    for i in range(n):
+        ia, ib = rng.randrange(16), rng.randrange(16)
+        na, nb = rng.randrange(2), rng.randrange(2)
+        if i % 10 == 0:
+            ib, nb = ia, na          # doubling
+        if i % 10 == 1:
+            ib, nb = ia, 1 - na      # cancellation
+        cases.append((ia, na, ib, nb))
+    INF = ([0] * 13, [0] * 13)
+    enc = lambda p: INF if p is None else _affine(p)  # noqa: E731
+    A = [enc(pts[ia]) for ia, _, _, _ in cases]
+    Bp = [enc(pts[ib]) for _, _, ib, _ in cases]
+    A[20] = INF                 # a at infinity
+    Bp[30] = INF                # b at infinity
+    A[40], Bp[40] = INF, INF    # both
+    flat = lambda rows: (ctypes.c_int32 * (13 * n))(*[v for r in rows for v in r])  # noqa: E731
+    out = (ctypes.c_int32 * (27 * n))()
+    lib.f30_pair_batch(flat([a[0] for a in A]), flat([a[1] for a in A]), flat([b[0] for b in Bp]), flat([b[1] for b in Bp]),
+                       (ctypes.c_int * n)(*[c[1] for c in cases]), (ctypes.c_int * n)(*[c[3] for c in cases]), n, out)
+    out = list(out)
+    neg = lambda p, s: p if not s else (p[0], (-p[1]) % P)  # noqa: E731
+    seen = set()
+    for i, (ia, na, ib, nb) in enumerate(cases):
+        kind = out[27 * i]
+        seen.add(kind)
+        pa = None if A[i] is INF else neg(pts[ia], na)
+        pb = None if Bp[i] is INF else neg(pts[ib], nb)
+        want = _ec_add(pa, pb)
+        if kind in (1, 2):
+            x3, y3 = value(out[27 * i + 1:27 * i + 14]), value(out[27 * i + 14:27 * i + 27])
+            rinv = pow(RQ, -1, P)
+            assert (x3 * rinv % P, y3 * rinv % P) == want, i
+            assert abs(x3) < 2 * P and abs(y3) < 1.4 * P
+        elif kind == 3:
+            assert want is None, i
+        elif kind == 4:
+            assert pb is None and want == pa
+        elif kind == 5:
+            assert pa is None and want == pb
+        else:
+            raise AssertionError(kind)
+    assert seen == {1, 2, 3, 4, 5}

@@ -3,6 +3,7 @@ and is compared, as 48-byte compressed G1 encodings (reference src/curves.rs:99-
 against the CPU oracle on the same inputs and against tests/golden/golden.json.  Bit-exact: this is
 integer work, there is no tolerance.  Shapes follow the reference's own round-trip tests
 (src/lib.rs:16-33, 51-94) and benches (benches/polynomial_commitment.rs, evaluation_proof.rs)."""
+import os
 import random
 
 import numpy as np
@@ -692,6 +693,134 @@ def test_failed_workspace_allocation_leaves_no_half_ready_context(oracle, golden
         eng.close()
 
 
+def test_affine_pair_front_end_is_bit_exact(golden):
+    """KZG_ACCUM_PAIRS=1 (msm_accum.hip: pairs of references added in affine coordinates with one shared safegcd
+    inversion per lane, then ONE mixed addition per pair) is opt-in -- it measured slower -- but stays bit-exact:
+    golden commitment / proof at 2^16, a polynomial with all coefficients equal (every pair is a doubling or meets the
+    same bucket's running sum) and degenerate SRS secrets (all points equal, opposite, at infinity), against the
+    default path in the same process image.  The switch is read once per process, hence the child process."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import kzg_poly_commit_exploration_amd as K
+golden = json.load(open(os.path.join(%r, "tests", "golden", "golden.json")))
+secret = bytes.fromhex(golden["secret_be"])
+d = 1 << 16
+r = K.R_MODULUS
+vals, p5 = [], 1
+for _ in range(d + 1):
+    vals.append((p5 + 10) %% r)
+    p5 = p5 * 5 %% r
+c = K.scalars_to_limbs(vals)
+z = K.Scalar((pow(5, d, r) + 20) %% r)
+out = {}
+eng = K.SetupArtifactsGenerator(secret).take(d + 1)
+y = eng.evaluate_limbs(c, z)
+out["commit"] = eng.commit_limbs(c).compress().hex()
+out["proof"] = eng.open_limbs(c, z, y).compress().hex()
+out["ones"] = eng.commit_limbs(K.scalars_to_limbs([1] * (d + 1))).compress().hex()
+out["small"] = eng.commit_limbs(K.scalars_to_limbs([(i * 7919) %% 5 for i in range(d + 1)])).compress().hex()
+eng.close()
+for name, s in (("one", 1), ("zero", 0), ("minus_one", r - 1)):
+    e2 = K.SetupArtifactsGenerator(s.to_bytes(32, "big")).take(40000)
+    out["secret_" + name] = e2.commit_limbs(c[:40000]).compress().hex()
+    e2.close()
+print(json.dumps(out))
+""" % (root, root)
+    res = {}
+    for mode in ("0", "1"):
+        # few lanes -> long segments (the front end only runs on segments of at least 16 references)
+        env = dict(os.environ, KZG_ACCUM_PAIRS=mode, KZG_ACCUM_LANES="4096")
+        p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[mode] = __import__("json").loads(p.stdout.strip().splitlines()[-1])
+    case = _case(golden, 1 << 16)
+    assert res["1"]["commit"] == case["commit"] and res["1"]["proof"] == case["proof"]
+    assert res["1"] == res["0"]
+
+
+# ---------------------------------------------------------------- SRS wire / on-disk forms (SURVEY.md section 8f-4)
+
+def test_srs_binary_cache_affine_and_compressed_forms(engines, oracle, golden, tmp_path):
+    """kzg_srs_save -> kzg_srs_load_file round trip equals kzg_srs_read_g1; kzg_srs_load_affine and the on-device
+    decompression of kzg_srs_load_compressed (what setup.json holds: reference src/curves.rs:99-183) give the same
+    resident SRS, the same commitments and proofs; malformed input is refused like blst_p1_uncompress refuses it."""
+    d = 2500
+    n = d + 1
+    src = engines.bench_srs(SMALL_N)
+    assert SMALL_N == n
+    want = src.srs_read(0, n)
+    c, z, y = _bench_poly(oracle, d)
+    case = _case(golden, d)
+    path = str(tmp_path / "srs.bin")
+    src.srs_save(path)
+    assert os.path.getsize(path) == 128 + 96 * n
+
+    def check(eng):
+        assert eng.srs_len() == n
+        assert np.array_equal(eng.srs_read(0, n), want)
+        assert eng.commit_limbs(c).compress().hex() == case["commit"]
+        assert eng.open_limbs(c, z, y).compress().hex() == case["proof"]
+
+    for make in (lambda: K.Engine(0), lambda: K.Engine(devices=[0, 0, 0])):
+        eng = make()
+        try:
+            eng.srs_load_file(path)
+            check(eng)
+            eng.srs_load_affine(want[:, :12])
+            check(eng)
+            blob = b"".join(K.G1Point(p).compress() for p in want)
+            eng.srs_load_compressed(blob)
+            check(eng)
+            # a point at infinity in the middle survives every form
+            with_inf = bytearray(blob)
+            with_inf[48 * 7:48 * 8] = bytes([0xC0]) + bytes(47)
+            eng.srs_load_compressed(bytes(with_inf))
+            back = eng.srs_read(0, 9)
+            assert not back[7].any() and np.array_equal(back[8], want[8]) and np.array_equal(back[6], want[6])
+            # malformed: x not on the curve / flag bits / x >= p
+            for idx, mutate in ((5, lambda b: b[:47] + bytes([b[47] ^ 1])),      # (almost surely) not a curve point
+                                (9, lambda b: bytes([b[0] & 0x7F]) + b[1:]),      # compressed flag cleared
+                                (11, lambda b: bytes([0x9F]) + bytes([0xFF]) * 47)):  # x >= p
+                bad = bytearray(blob)
+                bad[48 * idx:48 * idx + 48] = mutate(bytes(blob[48 * idx:48 * idx + 48]))
+                if idx == 5 and oracle_accepts_x(bytes(bad[48 * idx:48 * idx + 48])):
+                    continue
+                with pytest.raises(K.KzgError) as ei:
+                    eng.srs_load_compressed(bytes(bad))
+                assert ei.value.status == K.KZG_ERR_INVALID_ARG and ei.value.bad_index == idx
+                assert eng.srs_len() == 0
+        finally:
+            eng.close()
+    # a truncated or foreign file is refused
+    with open(path, "rb") as fh:
+        data = fh.read()
+    bad_path = str(tmp_path / "bad.bin")
+    eng = K.Engine(0)
+    try:
+        for blob2 in (data[:-96], data[:200] + bytes([data[200] ^ 0xFF]) + data[201:], b"NOTASRS" + data[7:]):
+            with open(bad_path, "wb") as fh:
+                fh.write(blob2)
+            with pytest.raises(K.KzgError):
+                eng.srs_load_file(bad_path)
+    finally:
+        eng.close()
+
+
+def oracle_accepts_x(enc):
+    """does the host's uncompress (on-curve check, as blst) accept this encoding?"""
+    try:
+        K.G1Point.uncompress(enc)
+        return True
+    except K.KzgError:
+        return False
+
+
 # ---------------------------------------------------------------- multi-device context (kzg_ctx_create_multi)
 
 def _device_lists():
@@ -931,6 +1060,46 @@ def test_batch_of_openings_and_their_verification(twin, golden):
         ys_bad[b // 2] = K.Scalar((ys[b // 2].v + 1) % K.R_MODULUS)
         verdicts = K.verify_proof_batch(commitments, proofs, zs, ys_bad, s_g2)
         assert verdicts == [i != b // 2 for i in range(b)]
+    finally:
+        eng.close()
+
+
+def test_config5_batch_of_eight_degree_2_20_openings_and_their_verification(engines, oracle, twin, golden):
+    """BASELINE config 5 at FULL size, one GPU's share: 8 openings of degree-2^20 polynomials in one
+    kzg_open_batch_submit (kzg_set_max_batch(8) at 2^20 + 1 points), each at its own point.  The opening at the
+    reference bench's point must equal the golden proof; all eight must pass the reference's pairing check
+    (kzg_verify_proof_batch, src/polynomial.rs:276-294) against the golden commitment, and a wrong claimed value is
+    rejected for exactly that opening."""
+    import pairing_twin as PT
+
+    d = 1 << 20
+    n = d + 1
+    case = _case(golden, d)
+    secret = bytes.fromhex(golden["secret_be"])
+    s = int.from_bytes(secret, "big") % K.R_MODULUS
+    c, z0, y0 = _bench_poly(oracle, d)
+    eng = K.SetupArtifactsGenerator(secret).take(n)
+    try:
+        assert eng.set_max_batch(8) == 8
+        r = K.R_MODULUS
+        zs = [z0] + [K.Scalar((z0.v * (k + 2) + 12345 * k) % r) for k in range(1, 8)]
+        ys = [eng.evaluate_limbs(c, z) for z in zs]
+        assert ys[0] == y0
+        proofs = eng.open_batch_limbs([c] * 8, zs, ys)
+        assert not any(isinstance(p, K.KzgError) for p in proofs)
+        assert proofs[0].compress().hex() == case["proof"]
+        assert len({p.compress() for p in proofs}) == 8
+        commitment = K.G1Point.uncompress(bytes.fromhex(case["commit"]))
+        (xa, xb), (ya, yb) = PT.g2_mul(PT.G2, s)
+        mont = lambda v: [((v << 384) % twin.P >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]  # noqa: E731
+        s_g2 = mont(xa) + mont(xb) + mont(ya) + mont(yb) + mont(1) + mont(0)
+        assert K.verify_proof_batch([commitment] * 8, proofs, zs, ys, s_g2) == [True] * 8
+        ys_bad = list(ys)
+        ys_bad[5] = K.Scalar((ys[5].v + 1) % r)
+        assert K.verify_proof_batch([commitment] * 8, proofs, zs, ys_bad, s_g2) == [i != 5 for i in range(8)]
+        # the batched commitments of the same 8 polynomials at full size
+        commits = eng.commit_batch_limbs([c] * 8)
+        assert all(g.compress().hex() == case["commit"] for g in commits)
     finally:
         eng.close()
 

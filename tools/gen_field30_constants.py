@@ -46,6 +46,10 @@ if __name__ == "__main__":
     emit("field30_p_u30.inc", "p, unsigned radix-2^30 digits", [(P >> (B * i)) & ((1 << B) - 1) for i in range(N)])
     emit("field30_c1170.inc", "2^1170 mod p, balanced radix-2^30 digits: turns v^-1 into the Montgomery form of the inverse",
          balanced(centered(pow(2, 1170, P))))
+    emit("field30_c780.inc", "2^780 mod p, balanced radix-2^30 digits: turns a plain integer into Montgomery form (R'^2)",
+         balanced(centered(pow(2, 780, P))))
+    emit("field30_half.inc", "(p - 1) / 2, balanced radix-2^30 digits (canonical form: the sign rule of the compressed encoding)",
+         balanced((P - 1) // 2))
     one = pow(2, 390, P)
     if one > P // 2:
         one -= P

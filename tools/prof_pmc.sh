@@ -6,7 +6,7 @@ set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-B="python3 bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline"
+B="python3 bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline --no-extras"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rm -rf gpurun_out/pmc_$tag

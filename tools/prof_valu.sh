@@ -4,7 +4,7 @@ set -o pipefail
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-B="python3 bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline"
+B="python3 bench.py --steps 4 --warmup 1 --slots 1 --no-cpu-baseline --no-extras"
 i=0
 for grp in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "GRBM_GUI_ACTIVE GRBM_COUNT" "VALUBusy" "VALUUtilization"; do
   i=$((i+1)); rm -rf gpurun_out/valu_$i
