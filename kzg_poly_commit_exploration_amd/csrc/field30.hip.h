@@ -204,11 +204,11 @@ KZG_HD Fq fq_sqr(const Fq& a) {
 
 // v == 0 (mod p) for |v| < 3.5 p.  The integer is k*p with |k| <= 3; its residue mod 2^30 only depends on digit 0,
 // so seven compares on one word reject everything but ~2^-27 of the non-zero values; the exact test runs then.
+// (by value: a reference parameter of a real call would pin every tested element in private memory)
 #if defined(__HIPCC__)
-static __host__ __device__ __noinline__ bool fq_is_zero_slow(const Fq& a_in) {
-    const Fq a = a_in;
+static __host__ __device__ __noinline__ bool fq_is_zero_slow(Fq a) {
 #else
-inline bool fq_is_zero_slow(const Fq& a) {
+inline bool fq_is_zero_slow(Fq a) {
 #endif
     const Fq c = fq_canon_digits(a);
     // k*p in canonical balanced digits, k = -3..3

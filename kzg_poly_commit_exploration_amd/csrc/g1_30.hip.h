@@ -30,6 +30,14 @@ struct XYZZ30 {
     Fq X, Y, ZZ, ZZZ;
 };
 
+// the Montgomery one for the (rare) "accumulator was at infinity" branch: a real call on the device, so that the
+// compiler does not materialise its 13 digits in registers, twice, in front of the branch on every addition
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __noinline__ Fq fq_one_cold() { return fq_one(); }
+#else
+KZG_HD Fq fq_one_cold() { return fq_one(); }
+#endif
+
 KZG_HD bool fq_all_zero(const Fq& a) {
     int32_t o = 0;
 #pragma unroll
@@ -92,8 +100,8 @@ KZG_HD bool xyzz30_madd_head(XYZZ30& acc, const Affine30& p_in, bool neg, Fq& P,
     if (xyzz30_is_inf(acc)) {
         acc.X = p_in.x;
         acc.Y = py;
-        acc.ZZ = fq_one();
-        acc.ZZZ = fq_one();
+        acc.ZZ = fq_one_cold();
+        acc.ZZZ = acc.ZZ;
         return false;
     }
     P = fq_norm(fq_sub_raw(fq_mul(p_in.x, acc.ZZ), acc.X));  // U2 - X1

@@ -12,10 +12,17 @@
 //      z^(L 2^s), one Fr product per step), workgroup aggregates out;
 //   2. one workgroup scans the aggregates (multiplier z^(L*256); each lane takes a run of blocks);
 //   3. every lane replays its chunk from its now-known carry and writes q.
+// Every power of z a lane needs (z^8 and its repeated squares for the scan inside a workgroup, z^2048 and the
+// powers of the block stage, the 2 x 16 entry table of the replay) is computed ONCE on the host (~60 Fr products,
+// host_fr.hpp) and travels as a kernel argument: the per-lane chains of dependent Fr products drop from 28 / 31 / 22
+// to 16 / 12 / 10 in the three kernels, which is what these latency-bound launches cost.
 // Algorithmic bytes: 32 B read + 32 B written per coefficient; the chunk
 // is read twice (the second time mostly from L2 / Infinity Cache).  HBM / latency bound.
 #include "engine.h"
 #include "field.hip.h"
+#include "host_fr.hpp"
+
+#include <cstring>
 
 namespace kzg {
 
@@ -48,21 +55,22 @@ KZG_DEV Fr fr_from_arg(const FrArg& a) {
     for (int i = 0; i < 8; i++) r.l[i] = a.l[i];
     return r;
 }
-KZG_DEV Fr fr_pow_u32(Fr base, uint32_t e) {
-    Fr acc = Fr::one();
-    while (e) {
-        if (e & 1u) acc = fe_mul(acc, base);
-        base = fe_mul(base, base);
-        e >>= 1;
-    }
-    return acc;
-}
-
+// powers of z prepared on the host (launch_quotient)
+struct PolyPowers {
+    FrArg z;
+    FrArg zl_sq[8];    // (z^L)^(2^s): multipliers of the scan inside a workgroup
+    FrArg zb;          // z^(L * 256): one workgroup up
+    FrArg zbp_sq[8];   // (zb^per)^(2^s): multipliers of the scan over the lanes of the block stage
+    FrArg pa[16];      // (z^L)^(16 e)
+    FrArg pb[16];      // (z^L)^e
+};
 // Kogge-Stone suffix scan over the workgroup: v_t <- sum_{u >= t} v_u * mult^(u - t)
 template <int BLOCK>
-KZG_DEV Fr block_suffix_scan(Fr v, Fr mult, uint32_t* lds /* BLOCK * 8 words */) {
+KZG_DEV Fr block_suffix_scan(Fr v, const FrArg* mults /* mult^(2^s), s < log2(BLOCK) */, uint32_t* lds /* BLOCK * 8 words */) {
     const int t = threadIdx.x;
-    for (int off = 1; off < BLOCK; off <<= 1) {
+    int s = 0;
+    for (int off = 1; off < BLOCK; off <<= 1, s++) {
+        const Fr mult = fr_from_arg(mults[s]);
 #pragma unroll
         for (int i = 0; i < 8; i++) lds[i * BLOCK + t] = v.l[i];
         __syncthreads();
@@ -73,17 +81,16 @@ KZG_DEV Fr block_suffix_scan(Fr v, Fr mult, uint32_t* lds /* BLOCK * 8 words */)
             v = fe_add(v, fe_mul(mult, o));
         }
         __syncthreads();
-        mult = fe_mul(mult, mult);
     }
     return v;
 }
 
-__global__ void __launch_bounds__(kPolyBlock) k_poly_chunks(const uint32_t* __restrict__ coeffs, uint32_t n, FrArg zarg,
+__global__ void __launch_bounds__(kPolyBlock) k_poly_chunks(const uint32_t* __restrict__ coeffs, uint32_t n, PolyPowers pw,
                                                             uint32_t* __restrict__ d_chunk,
                                                             uint32_t* __restrict__ d_block,
                                                             uint32_t* __restrict__ d_flags) {
     __shared__ uint32_t lds[kPolyBlock * 8];
-    const Fr z = fr_from_arg(zarg);
+    const Fr z = fr_from_arg(pw.z);
     const uint32_t t = blockIdx.x * kPolyBlock + threadIdx.x;
     const uint32_t base = t * kPolyL;
     Fr h = Fr::zero();
@@ -99,8 +106,7 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_chunks(const uint32_t* __re
         }
     }
     if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&d_flags[0], 1u);
-    Fr zl = fr_pow_u32(z, kPolyL);
-    h = block_suffix_scan<kPolyBlock>(h, zl, lds);
+    h = block_suffix_scan<kPolyBlock>(h, pw.zl_sq, lds);
     store_fr(d_chunk + (size_t)t * 8, h);
     if (threadIdx.x == 0) store_fr(d_block + (size_t)blockIdx.x * 8, h);
 }
@@ -110,11 +116,10 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_chunks(const uint32_t* __re
 // 256 lanes (one wave per SIMD, 86 VGPRs): small enough to start beside two resident accumulation waves of
 // another slot -- the former 1024-lane version needed 4 x 86 VGPRs per SIMD and waited ~1 ms for them.
 // Lane t owns `per` consecutive blocks: Horner over its blocks, Kogge-Stone across lanes, replay.
-__global__ void __launch_bounds__(kPolyBlock) k_poly_blocks(uint32_t* __restrict__ d_block, uint32_t nblocks, FrArg zarg,
+__global__ void __launch_bounds__(kPolyBlock) k_poly_blocks(uint32_t* __restrict__ d_block, uint32_t nblocks, PolyPowers pw,
                                                             uint32_t* __restrict__ d_result) {
     __shared__ uint32_t lds[kPolyBlock * 8];
-    const Fr z = fr_from_arg(zarg);
-    const Fr zb = fr_pow_u32(z, kPolyTile);  // one block up
+    const Fr zb = fr_from_arg(pw.zb);  // one block up
     const uint32_t t = threadIdx.x;
     const uint32_t per = (nblocks + kPolyBlock - 1) / kPolyBlock;
     const uint32_t lo = t * per;
@@ -122,7 +127,7 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_blocks(uint32_t* __restrict
     Fr h = Fr::zero();
     for (uint32_t u = hi; u-- > lo;) h = fe_add(fe_mul(h, zb), load_fr(d_block + (size_t)u * 8));
     // H_t = sum_{v >= t} h_v * (zb^per)^(v - t)
-    Fr H = block_suffix_scan<kPolyBlock>(h, fr_pow_u32(zb, per), lds);
+    Fr H = block_suffix_scan<kPolyBlock>(h, pw.zbp_sq, lds);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 8; i++) lds[i * kPolyBlock + t] = H.l[i];
@@ -140,32 +145,18 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_blocks(uint32_t* __restrict
     if (t == 0) store_fr(d_result, s);  // S[0] = P(z)
 }
 
-__global__ void __launch_bounds__(kPolyBlock) k_poly_apply(const uint32_t* __restrict__ coeffs, uint32_t n, FrArg zarg,
+__global__ void __launch_bounds__(kPolyBlock) k_poly_apply(const uint32_t* __restrict__ coeffs, uint32_t n, PolyPowers pw,
                                                            const uint32_t* __restrict__ d_chunk,
                                                            const uint32_t* __restrict__ d_block,
                                                            uint32_t* __restrict__ d_q) {
-    __shared__ uint32_t s_pow[2][16][8];  // zl^(16a), zl^b
-    const Fr z = fr_from_arg(zarg);
+    const Fr z = fr_from_arg(pw.z);
     const int tl = threadIdx.x;
     const uint32_t t = blockIdx.x * kPolyBlock + tl;
-    if (tl < 32) {
-        Fr zl = fr_pow_u32(z, kPolyL);
-        int which = tl >> 4, e = tl & 15;
-        Fr p = fr_pow_u32(zl, which == 0 ? 16u * e : (uint32_t)e);
-#pragma unroll
-        for (int i = 0; i < 8; i++) s_pow[which][e][i] = p.l[i];
-    }
-    __syncthreads();
     // carry into this lane's chunk = S at the first coefficient of the next chunk
     Fr blk_carry = load_fr(d_block + (size_t)blockIdx.x * 8);
     Fr h;
     uint32_t dist = (uint32_t)(kPolyBlock - 1 - tl);  // chunks between the next chunk and the block end
-    Fr pa, pb;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        pa.l[i] = s_pow[0][dist >> 4][i];
-        pb.l[i] = s_pow[1][dist & 15][i];
-    }
+    const Fr pa = fr_from_arg(pw.pa[dist >> 4]), pb = fr_from_arg(pw.pb[dist & 15]);  // (z^L)^dist = pa * pb
     Fr scaled = fe_mul(fe_mul(pa, pb), blk_carry);
     if (tl + 1 < kPolyBlock) {
         h = fe_add(load_fr(d_chunk + (size_t)(t + 1) * 8), scaled);
@@ -187,15 +178,36 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_apply(const uint32_t* __res
 void launch_quotient(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const uint32_t z_mont[8], uint32_t* d_q,
                      PolyScratch sc) {
     if (n == 0) return;
-    FrArg z;
-    for (int i = 0; i < 8; i++) z.l[i] = z_mont[i];
-    uint32_t nblocks = (n + kPolyTile - 1) / kPolyTile;
-    hipLaunchKernelGGL(k_poly_chunks, dim3(nblocks), dim3(kPolyBlock), 0, s, d_coeffs, n, z, sc.d_chunk, sc.d_block,
-                       sc.d_flags);
-    hipLaunchKernelGGL(k_poly_blocks, dim3(1), dim3(kPolyBlock), 0, s, sc.d_block, nblocks, z, sc.d_result);
+    namespace hf = kzg_host;
+    const uint32_t nblocks = (n + kPolyTile - 1) / kPolyTile;
+    const uint32_t per = (nblocks + kPolyBlock - 1) / kPolyBlock;  // blocks per lane of the block stage
+    PolyPowers pw;
+    auto put = [](FrArg& dst, const hf::Fr& v) { std::memcpy(dst.l, v.l, 32); };
+    hf::Fr z;
+    std::memcpy(z.l, z_mont, 32);
+    put(pw.z, z);
+    hf::Fr zl = hf::fr_pow(z, kPolyL), m = zl;
+    for (int k = 0; k < 8; k++) {  // zl^(2^k); after the loop m = zl^256 = z^(L * 256)
+        put(pw.zl_sq[k], m);
+        m = hf::fr_mul(m, m);
+    }
+    put(pw.zb, m);
+    hf::Fr mb = hf::fr_pow(m, per);
+    for (int k = 0; k < 8; k++) {
+        put(pw.zbp_sq[k], mb);
+        mb = hf::fr_mul(mb, mb);
+    }
+    hf::Fr zl16 = hf::fr_pow(zl, 16), a = hf::kFrOne, b = hf::kFrOne;
+    for (int e = 0; e < 16; e++) {
+        put(pw.pa[e], a);
+        put(pw.pb[e], b);
+        a = hf::fr_mul(a, zl16);
+        b = hf::fr_mul(b, zl);
+    }
+    hipLaunchKernelGGL(k_poly_chunks, dim3(nblocks), dim3(kPolyBlock), 0, s, d_coeffs, n, pw, sc.d_chunk, sc.d_block, sc.d_flags);
+    hipLaunchKernelGGL(k_poly_blocks, dim3(1), dim3(kPolyBlock), 0, s, sc.d_block, nblocks, pw, sc.d_result);
     if (d_q && n > 1)
-        hipLaunchKernelGGL(k_poly_apply, dim3(nblocks), dim3(kPolyBlock), 0, s, d_coeffs, n, z, sc.d_chunk, sc.d_block,
-                           d_q);
+        hipLaunchKernelGGL(k_poly_apply, dim3(nblocks), dim3(kPolyBlock), 0, s, d_coeffs, n, pw, sc.d_chunk, sc.d_block, d_q);
 }
 
 }  // namespace kzg
