@@ -168,6 +168,44 @@ KZG_HD Fq fq_mul(const Fq& a, const Fq& b) {
     return r;
 }
 
+// (a * b - c * d) / 2^390 (mod p) with ONE Montgomery reduction: both digit products are accumulated into the same
+// columns.  Column bound: 2 x 12 full products of at most (2^29 + 4)^2 plus the m * p part,
+// 6.0 * 2^60 + 1.55 * 2^60 < 2^63 -- so ALL FOUR operands must be weakly normalised (|digit| <= 2^29 + 4; no raw sums
+// here), |a b - c d| < 2^771.  Saves 169 multiply-adds and the carry work of one product wherever the group law
+// subtracts two products (Y3 = R (Q - X3) - Y1 PPP).
+KZG_HD Fq fq_mul_sub(const Fq& a, const Fq& b, const Fq& c, const Fq& d) {
+    int32_t m[kQ];
+    Fq r;
+    int64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < kQ; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (int64_t)a.d[i] * b.d[k - i];
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc -= (int64_t)c.d[i] * d.d[k - i];
+#pragma unroll
+        for (int j = 0; j < k; j++) acc += (int64_t)m[j] * fq_pd(k - j);
+        m[k] = fq_sext30((uint32_t)acc * kQN0);
+        acc += (int64_t)m[k] * fq_pd(0);
+        acc >>= kQBits;
+        KZG_F30_FENCE(acc);
+    }
+#pragma unroll
+    for (int k = kQ; k < 2 * kQ - 1; k++) {
+#pragma unroll
+        for (int i = k - kQ + 1; i < kQ; i++) acc += (int64_t)a.d[i] * b.d[k - i];
+#pragma unroll
+        for (int i = k - kQ + 1; i < kQ; i++) acc -= (int64_t)c.d[i] * d.d[k - i];
+#pragma unroll
+        for (int j = k - kQ + 1; j < kQ; j++) acc += (int64_t)m[j] * fq_pd(k - j);
+        r.d[k - kQ] = fq_sext30((uint32_t)acc);
+        acc = fq_round_shift(acc);
+        KZG_F30_FENCE(acc);
+    }
+    r.d[kQ - 1] = (int32_t)acc;
+    return r;
+}
+
 // Montgomery square: cross products once against the doubled operand (91 instead of 169 digit products)
 KZG_HD Fq fq_sqr(const Fq& a) {
     int32_t m[kQ], dbl[kQ];

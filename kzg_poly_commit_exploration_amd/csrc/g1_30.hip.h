@@ -93,7 +93,7 @@ KZG_HD void xyzz30_dbl_inplace(XYZZ30& a) { xyzz30_dbl_body(a); }
 // point between them (the accumulation kernel issues the gather of its next point there):
 //   xyzz30_madd_head  consumes the point: returns false when the addition is already complete (a trivial or
 //                     exceptional case), true with P = U2 - X1 and R = S2 - Y1 otherwise;
-//   xyzz30_madd_tail  the remaining 6M + 2S on (acc, P, R).
+//   xyzz30_madd_tail  the remaining 6M + 2S on (acc, P, R); the last two products share one reduction.
 KZG_HD bool xyzz30_madd_head(XYZZ30& acc, const Affine30& p_in, bool neg, Fq& P, Fq& R) {
     if (fq_all_zero(p_in.x) && fq_all_zero(p_in.y)) return false;
     const Fq py = fq_cneg(p_in.y, neg);
@@ -126,11 +126,13 @@ KZG_HD void xyzz30_madd_tail(XYZZ30& acc, const Fq& P, const Fq& R) {
     KZG_SB30();
     acc.ZZZ = fq_mul(acc.ZZZ, PPP);
     KZG_SB30();
-    const Fq YP = fq_mul(acc.Y, PPP);
-    KZG_SB30();
     const Fq X3 = fq_norm_wide(fq_sub_raw(fq_sub_raw(fq_sqr(R), PPP), fq_add_raw(Q, Q)));  // digits up to 2^31
     KZG_SB30();
-    acc.Y = fq_norm(fq_sub_raw(fq_mul(R, fq_sub_raw(Q, X3)), YP));
+#ifdef KZG_NO_MUL_SUB  // A/B: two products, two reductions (round 2's first form)
+    acc.Y = fq_norm(fq_sub_raw(fq_mul(R, fq_sub_raw(Q, X3)), fq_mul(acc.Y, PPP)));
+#else
+    acc.Y = fq_mul_sub(R, fq_norm(fq_sub_raw(Q, X3)), acc.Y, PPP);  // R (Q - X3) - Y1 PPP, one reduction
+#endif
     KZG_SB30();
     acc.X = X3;
 }
@@ -139,7 +141,7 @@ KZG_HD void xyzz30_madd(XYZZ30& acc, const Affine30& p_in, bool neg) {
     if (xyzz30_madd_head(acc, p_in, neg, P, R)) xyzz30_madd_tail(acc, P, R);
 }
 
-// acc += b (add-2008-s: 12M + 2S), complete
+// acc += b (add-2008-s: 12M + 2S, the last two products sharing one reduction), complete
 KZG_HD void xyzz30_add(XYZZ30& acc, const XYZZ30& b) {
     if (xyzz30_is_inf(b)) return;
     if (xyzz30_is_inf(acc)) {
@@ -169,11 +171,9 @@ KZG_HD void xyzz30_add(XYZZ30& acc, const XYZZ30& b) {
     KZG_SB30();
     acc.ZZZ = fq_mul(fq_mul(acc.ZZZ, b.ZZZ), PPP);
     KZG_SB30();
-    const Fq YP = fq_mul(S1, PPP);
-    KZG_SB30();
     const Fq X3 = fq_norm_wide(fq_sub_raw(fq_sub_raw(fq_sqr(R), PPP), fq_add_raw(Q, Q)));
     KZG_SB30();
-    acc.Y = fq_norm(fq_sub_raw(fq_mul(R, fq_sub_raw(Q, X3)), YP));
+    acc.Y = fq_mul_sub(R, fq_norm(fq_sub_raw(Q, X3)), S1, PPP);  // R (Q - X3) - S1 PPP, one reduction
     acc.X = X3;
 }
 

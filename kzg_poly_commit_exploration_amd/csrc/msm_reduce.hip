@@ -103,11 +103,14 @@ void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count) {
     TreeJobs jobs;
     jobs.count = count;
     // One lane per element gives the shortest chain (log2(len) dependent additions) but only ~1/log2(len)
-    // of the lane-steps do work.  With 48 KB of LDS and ~156 VGPRs a CU holds three workgroups, so beyond
-    // 3 x 256 workgroups a second round would start: lanes then pre-add several elements serially.
+    // of the lane-steps do work.  The kernel holds KZG_TREE_WAVES waves per SIMD (inlined additions: 300+ VGPRs, one
+    // wave), i.e. KZG_TREE_WAVES workgroups of 256 lanes per CU: beyond that a second round would start, which costs a
+    // whole tree's latency -- lanes then pre-add several elements serially instead (one more dependent addition per
+    // doubling).  (Round 1 assumed three resident workgroups; with one, 131072 one-element lanes ran as two rounds:
+    // 167 us per stage-1 launch at 65536 buckets.)
     uint64_t total = 0;
     for (uint32_t i = 0; i < count && i < 4; i++) total += (uint64_t)descs[i].groups * descs[i].len;
-    const uint64_t resident_lanes = 3ull * 256 * kTreeBlock;
+    const uint64_t resident_lanes = (uint64_t)KZG_TREE_WAVES * 256 * kTreeBlock;
     uint32_t per_lane = 1;
     while ((total + per_lane - 1) / per_lane > resident_lanes && per_lane < 64) per_lane <<= 1;
     uint32_t blocks = 0;

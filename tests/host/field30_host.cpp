@@ -18,6 +18,32 @@ void f30_mul(const int32_t* a, const int32_t* b, int32_t* r) {
     Fq z = fq_mul(x, y);
     memcpy(r, z.d, sizeof z.d);
 }
+void f30_mul_sub(const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d, int32_t* r) {
+    Fq x, y, z, w;
+    memcpy(x.d, a, sizeof x.d);
+    memcpy(y.d, b, sizeof y.d);
+    memcpy(z.d, c, sizeof z.d);
+    memcpy(w.d, d, sizeof w.d);
+    Fq o = fq_mul_sub(x, y, z, w);
+    memcpy(r, o.d, sizeof o.d);
+}
+// largest |column| / 2^48 of fq_mul_sub in exact arithmetic (sum of magnitudes: the worst sign pattern)
+int64_t f30_mul_sub_max_column(const int32_t* a, const int32_t* b, const int32_t* c, const int32_t* d) {
+    __int128 worst = 0;
+    for (int k = 0; k < 25; k++) {
+        __int128 mag = (__int128)1 << 34;  // carry in
+        for (int i = 0; i < 13; i++) {
+            int j = k - i;
+            if (j < 0 || j > 12) continue;
+            __int128 t = (__int128)a[i] * b[j], u = (__int128)c[i] * d[j];
+            mag += (t < 0 ? -t : t) + (u < 0 ? -u : u);
+            __int128 pm = (__int128)(1 << 29) * fq_pd(j);  // |m_i| <= 2^29 times |p_j|
+            mag += pm < 0 ? -pm : pm;
+        }
+        if (mag > worst) worst = mag;
+    }
+    return (int64_t)(worst >> 48);
+}
 void f30_sqr(const int32_t* a, int32_t* r) {
     Fq x;
     memcpy(x.d, a, sizeof x.d);
@@ -104,6 +130,15 @@ void f30_pair_batch(const int32_t* ax, const int32_t* ay, const int32_t* bx, con
     }
     delete[] prefix;
     delete[] kind;
+}
+
+// acc (4 x 13 digits) += b (4 x 13 digits): the general addition of the tree kernels
+void f30_add(int32_t* acc, const int32_t* b) {
+    XYZZ30 a, o;
+    memcpy(a.X.d, acc, 52); memcpy(a.Y.d, acc + 13, 52); memcpy(a.ZZ.d, acc + 26, 52); memcpy(a.ZZZ.d, acc + 39, 52);
+    memcpy(o.X.d, b, 52); memcpy(o.Y.d, b + 13, 52); memcpy(o.ZZ.d, b + 26, 52); memcpy(o.ZZZ.d, b + 39, 52);
+    xyzz30_add(a, o);
+    memcpy(acc, a.X.d, 52); memcpy(acc + 13, a.Y.d, 52); memcpy(acc + 26, a.ZZ.d, 52); memcpy(acc + 39, a.ZZZ.d, 52);
 }
 
 // the multiplier's column sums in exact arithmetic (__int128): returns the largest |column| / 2^48 seen

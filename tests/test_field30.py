@@ -292,3 +292,69 @@ def test_pair_batch_affine_sums_with_shared_inversion(lib):
         else:
             raise AssertionError(kind)
     assert seen == {1, 2, 3, 4, 5}
+
+
+def test_mul_sub_single_reduction(lib):
+    """fq_mul_sub(a, b, c, d) = (a b - c d) / 2^390 with one reduction; all operands weakly normalised"""
+    rng = random.Random(38)
+    lib.f30_mul_sub_max_column.restype = ctypes.c_int64
+    for it in range(2000):
+        a, b, c, d = (rand_lazy(rng, 383) for _ in range(4))
+        r = I13()
+        lib.f30_mul_sub(I13(*balanced(a)), I13(*balanced(b)), I13(*balanced(c)), I13(*balanced(d)), r)
+        v = value(list(r))
+        assert (v * RQ - (a * b - c * d)) % P == 0
+        assert all(-(1 << 29) <= x < (1 << 29) for x in list(r)[:12])
+        assert abs(v) < 0.62 * P + (abs(a * b - c * d) >> 390) + 1
+    # the contract's extreme: every digit at 2^29 + 4, signs arranged so that everything adds up
+    big = (1 << 29) + 4
+    for sa, sc in ((1, -1), (-1, 1)):
+        a = [sa * big] * 12 + [1 << 24]
+        b = [big] * 12 + [1 << 24]
+        c = [sc * big] * 12 + [1 << 24]
+        d = [big] * 12 + [1 << 24]
+        assert lib.f30_mul_sub_max_column(I13(*a), I13(*b), I13(*c), I13(*d)) < (1 << 15)  # < 2^63
+        r = I13()
+        lib.f30_mul_sub(I13(*a), I13(*b), I13(*c), I13(*d), r)
+        assert (value(list(r)) * RQ - (value(a) * value(b) - value(c) * value(d))) % P == 0
+
+
+def test_group_law_general_addition(lib):
+    """xyzz30_add (the tree kernels' addition): sums of XYZZ accumulators built by mixed additions, including equal
+    operands (doubling branch), opposite operands and infinity on either side"""
+    gx = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+    gy = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+    G = (gx, gy)
+    pts = [G]
+    for _ in range(11):
+        pts.append(_ec_add(pts[-1], G))
+    I52 = ctypes.c_int32 * 52
+    rng = random.Random(39)
+
+    def build(ks):
+        """accumulator holding sum of the signed multiples in ks (list of (index, neg)), and the affine value"""
+        acc = I52()
+        want = None
+        for idx, neg in ks:
+            px, py = _affine(pts[idx])
+            lib.f30_madd(acc, I13(*px), I13(*py), neg)
+            want = _ec_add(want, pts[idx] if not neg else (pts[idx][0], (-pts[idx][1]) % P))
+        return acc, want
+
+    def affine_of(acc):
+        X, Y, ZZ, ZZZ = (value(list(acc)[13 * k:13 * k + 13]) for k in range(4))
+        if ZZ == 0:
+            return None
+        return X * pow(ZZ, -1, P) % P, Y * pow(ZZZ, -1, P) % P
+
+    cases = [([(0, 0), (1, 0)], [(2, 0)]),            # 3G + 3G: equal group elements, different representations
+             ([(0, 0), (1, 0)], [(2, 1)]),            # 3G - 3G
+             ([], [(4, 0)]), ([(4, 0)], []), ([], [])]
+    for _ in range(60):
+        cases.append(([(rng.randrange(12), rng.randrange(2)) for _ in range(rng.randrange(1, 5))],
+                      [(rng.randrange(12), rng.randrange(2)) for _ in range(rng.randrange(1, 5))]))
+    for ka, kb in cases:
+        a, wa = build(ka)
+        b, wb = build(kb)
+        lib.f30_add(a, b)
+        assert affine_of(a) == _ec_add(wa, wb), (ka, kb)
