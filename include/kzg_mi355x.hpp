@@ -61,6 +61,8 @@ struct G1Point {  // blst_p1: {x, y, z} Jacobian, Montgomery; z == 0 <=> infinit
 class SetupArtifacts {  // owns one engine context = one GPU with the SRS resident
    public:
     explicit SetupArtifacts(int device = 0) { check(kzg_ctx_create(device, &ctx_)); }
+    // one context over several devices: SRS split by point range, commit / open sharded transparently
+    explicit SetupArtifacts(const std::vector<int>& devices) { check(kzg_ctx_create_multi(devices.data(), (int)devices.size(), &ctx_)); }
     ~SetupArtifacts() { kzg_ctx_destroy(ctx_); }
     SetupArtifacts(const SetupArtifacts&) = delete;
     SetupArtifacts& operator=(const SetupArtifacts&) = delete;
@@ -70,6 +72,10 @@ class SetupArtifacts {  // owns one engine context = one GPU with the SRS reside
     }
     // from the reference's own memory: &srs[0].g1, stride = sizeof(SetupArtifact)
     void load(const void* first_g1, size_t stride_bytes, size_t n) { check(kzg_srs_load_g1(ctx_, first_g1, stride_bytes, n), ctx_); }
+    // the 48-byte points of the CLI's setup.json (src/curves.rs:99-183), decompressed on the device
+    void load_compressed(const uint8_t* points48, size_t n) { check(kzg_srs_load_compressed(ctx_, points48, n, nullptr), ctx_); }
+    void save(const std::string& path) const { check(kzg_srs_save(ctx_, path.c_str()), ctx_); }   // binary affine cache
+    void load_file(const std::string& path) { check(kzg_srs_load_file(ctx_, path.c_str()), ctx_); }
     size_t len() const { return kzg_srs_len(ctx_); }
     kzg_ctx* ctx() const { return ctx_; }
 

@@ -41,7 +41,7 @@ namespace kzg {
 constexpr uint32_t kSerialSpan = 16;  // buckets spanning more segments than this go through the tree kernel
 constexpr uint32_t kSerialSpanFew = 4, kFewBuckets = 2048;  // threshold when there are at most kFewBuckets buckets
 constexpr int kChunk = 64;           // pieces per tree = lanes per workgroup of the tree passes
-constexpr int kTreeGrid = 2048;      // workgroups per tree pass (grid-stride over the work items)
+constexpr int kTreeGrid = 1024;      // workgroups per tree pass (grid-stride over the work items): one resident round at one wave per SIMD
 
 // one registered long bucket
 struct HeavyEntry {

@@ -393,6 +393,12 @@ __global__ void __launch_bounds__(256) k_fine_offsets(const uint32_t* __restrict
                     : bin_start(d_cnt_scanned, tiles, coarse_bins, bin, *d_total);
 }
 
+// Scatter of one chunk, staged through LDS: the references are first ranked inside the workgroup (one LDS cursor per
+// fine key, cursors start at the key's offset inside the chunk), stored in LDS in that order together with their
+// global destination, and then written out by consecutive lanes -- a key's run of this chunk is contiguous in global
+// memory, so a wave's 64 stores fall into a handful of 64-byte runs instead of 64 different ones (the direct form
+// issued 15.7 M separate 4-byte store transactions per commitment: 145 us alone at 2^20 terms).
+constexpr uint32_t kFineStage = 4096;  // references staged per round (16 KB + 16 KB of LDS)
 __global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const uint64_t* __restrict__ d_pairs,
                                                              const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
                                                              uint32_t fine_bits, uint32_t coarse_bins,
@@ -400,16 +406,81 @@ __global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const uint64_t* __r
                                                              const uint32_t* __restrict__ d_prefix,
                                                              const uint32_t* __restrict__ d_table_scanned,
                                                              uint32_t* __restrict__ d_sorted) {
-    __shared__ u32 s_cur[kFineMax];
+    __shared__ u32 s_cur[kFineMax];    // global cursor of every fine key for this chunk
+    __shared__ u32 s_cnt[kFineMax];    // round: references per key, then exclusive offsets, then local cursors
+    __shared__ u32 s_ref[kFineStage];  // round: references in key order
+    __shared__ u32 s_dst[kFineStage];  // round: their global positions
     FineChunk c;
     if (!locate_chunk(blockIdx.x, d_prefix, d_cnt_scanned, tiles, coarse_bins, *d_total, ch, c)) return;
     const uint32_t fine = 1u << fine_bits;
-    if (threadIdx.x < fine) s_cur[threadIdx.x] = d_table_scanned[(size_t)c.base * fine + (size_t)threadIdx.x * c.nch + c.j];
-    __syncthreads();
-    for (uint32_t e = c.beg + threadIdx.x; e < c.end; e += kSortBlock) {
-        uint64_t pr = d_pairs[e];
-        u32 pos = atomicAdd(&s_cur[(u32)(pr >> 32)], 1u);
-        d_sorted[pos] = (u32)pr;
+    const uint32_t t = threadIdx.x;
+    if (t < fine) s_cur[t] = d_table_scanned[(size_t)c.base * fine + (size_t)t * c.nch + c.j];
+    for (uint32_t r0 = c.beg; r0 < c.end; r0 += kFineStage) {
+        const uint32_t r1 = (c.end - r0 < kFineStage) ? c.end : r0 + kFineStage;
+        if (t < kFineMax) s_cnt[t] = 0;
+        __syncthreads();
+        // pass 1: count per key inside the round (pairs stay in registers: kFineStage / kSortBlock = 16 per lane)
+        uint64_t pr[kFineStage / kSortBlock];
+#pragma unroll
+        for (uint32_t q = 0; q < kFineStage / kSortBlock; q++) {
+            const uint32_t e = r0 + q * kSortBlock + t;
+            pr[q] = e < r1 ? d_pairs[e] : ~0ull;
+            if (e < r1) atomicAdd(&s_cnt[(u32)(pr[q] >> 32)], 1u);
+        }
+        __syncthreads();
+        // exclusive scan of the (at most 256) counts: one lane per key, Hillis-Steele in LDS
+        u32 mine = t < kFineMax ? s_cnt[t] : 0u;
+        u32 incl = mine;
+        __syncthreads();
+        if (t < kFineMax) s_ref[t] = incl;  // scratch for the scan (s_ref is free until pass 2)
+        __syncthreads();
+        for (uint32_t off = 1; off < kFineMax; off <<= 1) {
+            u32 add = (t < kFineMax && t >= off) ? s_ref[t - off] : 0u;
+            __syncthreads();
+            if (t < kFineMax) {
+                incl += add;
+                s_ref[t] = incl;
+            }
+            __syncthreads();
+        }
+        const u32 excl = incl - mine;
+        // global base of this key's run for THIS round = global cursor; local cursor = exclusive offset
+        u32 gbase = 0;
+        if (t < kFineMax) {
+            gbase = s_cur[t];
+            s_cur[t] = gbase + mine;  // next round continues behind it
+            s_cnt[t] = excl;
+        }
+        __syncthreads();
+        if (t < kFineMax) s_dst[t] = gbase - excl;  // global position = (gbase - excl) + local rank; parked per key
+        __syncthreads();
+        // pass 2: rank inside the round, park reference and destination in key order
+        u32 keep_dst[kFineStage / kSortBlock];
+        u32 keep_pos[kFineStage / kSortBlock];
+#pragma unroll
+        for (uint32_t q = 0; q < kFineStage / kSortBlock; q++) {
+            const uint32_t e = r0 + q * kSortBlock + t;
+            if (e < r1) {
+                const u32 key = (u32)(pr[q] >> 32);
+                const u32 pos = atomicAdd(&s_cnt[key], 1u);
+                keep_pos[q] = pos;
+                keep_dst[q] = s_dst[key] + pos;
+            }
+        }
+        __syncthreads();  // every lane has read s_dst[key] before it is overwritten
+#pragma unroll
+        for (uint32_t q = 0; q < kFineStage / kSortBlock; q++) {
+            const uint32_t e = r0 + q * kSortBlock + t;
+            if (e < r1) {
+                s_ref[keep_pos[q]] = (u32)pr[q];
+                s_dst[keep_pos[q]] = keep_dst[q];
+            }
+        }
+        __syncthreads();
+        // pass 3: consecutive lanes write consecutive ranks
+        const uint32_t cnt = r1 - r0;
+        for (uint32_t i = t; i < cnt; i += kSortBlock) d_sorted[s_dst[i]] = s_ref[i];
+        __syncthreads();
     }
 }
 
