@@ -41,8 +41,9 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 # loop of independent 32x32+64 multiply-adds reaches 33.4 T/s chip-wide and nothing hides behind it.
 VALU_MAD_PEAK_T = 33.4
 # executed v_mad_i64_i32 per mixed addition of the accumulation kernel (signed radix-2^30 field, field30.hip.h):
-# 8 products x 2 x 13^2 + 2 squarings x (91 + 13^2); counted in the ISA of k_bucket_accumulate (3224)
-MADS_PER_MADD = 8 * 338 + 2 * 260
+# 6 products x 2 x 13^2, 2 squarings x (91 + 13^2), and R (Q - X3) - Y1 PPP as two digit products under ONE
+# reduction (3 x 13^2); counted in the ISA of k_bucket_accumulate (3055)
+MADS_PER_MADD = 6 * 338 + 2 * 260 + 3 * 169
 
 
 def kernel_source_hash():
