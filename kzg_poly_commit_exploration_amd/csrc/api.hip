@@ -271,7 +271,8 @@ int setup_slots_impl(kzg_ctx* ctx) {
         HIP_TRY(ctx, hipMalloc(&s.d_buckets, (size_t)cfg.nb * B * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_part_a, (size_t)kMaxAccumLanes * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_part_b, (size_t)kMaxAccumLanes * kXyzzBytes));
-        HIP_TRY(ctx, hipMalloc(&s.d_pair_scratch, accumulate_pair_scratch_bytes(pairs)));
+        if (const size_t pair_bytes = accumulate_pair_scratch_bytes(pairs))  // only with KZG_ACCUM_PAIRS=1
+            HIP_TRY(ctx, hipMalloc(&s.d_pair_scratch, pair_bytes));
         HIP_TRY(ctx, hipMalloc(&s.d_heavy_ws, heavy_workspace_bytes()));
         HIP_TRY(ctx, hipMalloc(&s.d_arena, ctx->arena_records * B * kXyzzBytes));
         HIP_TRY(ctx, hipMalloc(&s.d_final, ctx->final_records * B * kXyzzBytes));

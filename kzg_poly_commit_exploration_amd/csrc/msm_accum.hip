@@ -466,8 +466,24 @@ uint32_t accumulate_lanes(uint64_t max_refs, bool alone) {
     return (uint32_t)lanes;
 }
 
+// KZG_ACCUM_PAIRS=1 selects the affine front end (segments of at least 16 references).  Off by default: bit-exact
+// (the GPU suite runs a child process under it) but SLOWER on MI355X -- measured at 2^20 terms, same box, 131072 lanes:
+// 3.66 ms per launch against 2.81 ms for plain mixed additions (3.20 ms without any prefetch, 3.85 ms with a
+// per-slot loop that let one lane's bucket boundary cost its wave an extra addition, 4.0-4.2 ms with the five pair
+// products as real calls).  The 3.9 field products a pair saves are eaten by what the product count does not show:
+// two carry passes and a zero test per affine sum, the prefix records, a second gather, the 64 + 16 LDS-DMA /
+// LDS reads per step, a loop body of 73 KB against a 64 KB instruction cache, and ~50 products' worth of
+// strictly serial division steps per lane for the shared inversion.
+bool accumulate_pairs_enabled() {
+    static const int pairs_mode = [] {
+        const char* v = std::getenv("KZG_ACCUM_PAIRS");
+        return v ? std::atoi(v) : 0;
+    }();
+    return pairs_mode != 0;
+}
 size_t accumulate_pair_scratch_bytes(uint64_t max_refs) {
-    // one 64-byte record per pair slot: at most max_refs / 2 + one per lane
+    // one 64-byte record per pair slot: at most max_refs / 2 + one per lane; nothing when the front end is off
+    if (!accumulate_pairs_enabled()) return 0;
     return (size_t)(max_refs / 2 + kMaxAccumLanes) * kPairRecU4 * 16;
 }
 
@@ -475,19 +491,7 @@ void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t
                               uint32_t nb, uint32_t lanes, void* d_buckets, void* d_part_a, void* d_part_b,
                               uint32_t lds_reserve_bytes, void* d_pair_scratch, uint64_t max_refs) {
     if (!lanes) return;
-    // KZG_ACCUM_PAIRS=1 selects the affine front end (segments of at least 16 references).  Off by default: bit-exact
-    // (the GPU suite runs under it too) but SLOWER on MI355X -- measured at 2^20 terms, same box, 131072 lanes:
-    // 3.66 ms per launch against 2.81 ms for plain mixed additions (3.20 ms without any prefetch, 3.85 ms with a
-    // per-slot loop that let one lane's bucket boundary cost its wave an extra addition, 4.0-4.2 ms with the five pair
-    // products as real calls).  The 3.9 field products a pair saves are eaten by what the product count does not show:
-    // two carry passes and a zero test per affine sum, the prefix records, a second gather, the 64 + 16 LDS-DMA /
-    // LDS reads per step, a loop body of 73 KB against a 64 KB instruction cache, and ~50 products' worth of
-    // strictly serial division steps per lane for the shared inversion.
-    static const int pairs_mode = [] {
-        const char* v = std::getenv("KZG_ACCUM_PAIRS");
-        return v ? std::atoi(v) : 0;
-    }();
-    if (pairs_mode && d_pair_scratch && max_refs / lanes >= 16) {
+    if (accumulate_pairs_enabled() && d_pair_scratch && max_refs / lanes >= 16) {
         hipLaunchKernelGGL(k_bucket_accumulate_pairs, dim3(lanes / kAccumBlock), dim3(kAccumBlock),
                            (kAccumBlock / 64) * 16 * 64 * 16 /* two point slots per wave */, s,
                            reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb, lanes,

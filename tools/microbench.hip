@@ -636,6 +636,18 @@ static int run_field30() {
     bool ok_madd = canon_eq(h + 24, h2 + 24) && canon_eq(h + 36, h2 + 36) && canon_eq(h + 48, h2 + 48) && canon_eq(h + 60, h2 + 60);
     printf("{\"probe\": \"field30_vs_fips\", \"mul_equal\": %s, \"sqr_equal\": %s, \"madd_equal\": %s}\n", ok_mul ? "true" : "false",
            ok_sqr ? "true" : "false", ok_madd ? "true" : "false");
+    // latency of ONE wave alone on the chip (what the finalisation / reduction trees pay per dependent addition)
+    {
+        reset();
+        double ms = time_kernel(k_fqmul, 1, 64, 5, dio, 200);
+        printf("{\"bench\": \"lone_wave_fp_mul_signed30\", \"us_per_product\": %.3f}\n", ms * 1e3 / 400.0);
+        reset();
+        ms = time_kernel(k_madd30, 1, 64, 5, dio, 64);
+        printf("{\"bench\": \"lone_wave_xyzz_madd_signed30\", \"us_per_addition\": %.3f}\n", ms * 1e3 / 64.0);
+        reset();
+        ms = time_kernel(k_madd30, 256, 64, 5, dio, 64);
+        printf("{\"bench\": \"one_wave_per_cu_xyzz_madd_signed30\", \"us_per_addition\": %.3f}\n", ms * 1e3 / 64.0);
+    }
     for (int wps = 1; wps <= 4; wps++) {
         int grid = cus * wps;
         const int fit = 200, block = 256;

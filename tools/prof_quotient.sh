@@ -1,0 +1,36 @@
+#!/bin/bash
+# HBM bytes of the quotient scan (k_poly_chunks / k_poly_blocks / k_poly_apply) from PMC counters, one counter group
+# per pass, on ten degree-2^20 openings run one at a time (tools/prof_latency.py): FETCH_SIZE, WRITE_SIZE (KiB).
+# Algorithmic bytes: 32 B read + 32 B written per coefficient = 64 MiB per opening.
+set -o pipefail
+cd "${GRAFT_REPO_ROOT:-.}"
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+for grp in "FETCH_SIZE" "WRITE_SIZE"; do
+  rm -rf gpurun_out/qpmc_$grp
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/qpmc_$grp -- python3 tools/prof_latency.py 1048576 open 10 > gpurun_out/qpmc_$grp.log 2>&1
+done
+python3 - <<'PY'
+import csv, glob, collections, json
+res = collections.defaultdict(lambda: collections.defaultdict(list))
+dur = collections.defaultdict(list)
+for f in glob.glob("gpurun_out/qpmc_*/*/*counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("kzg::", "")
+        if k.startswith("k_poly"):
+            res[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+out = {}
+for k, v in res.items():
+    out[k] = {c: sum(x) / len(x) for c, x in v.items()}
+    out[k]["kernel_us_profiled"] = sum(dur[k]) / len(dur[k])
+tot_r = sum(v.get("FETCH_SIZE", 0) for v in out.values()) * 1024
+tot_w = sum(v.get("WRITE_SIZE", 0) for v in out.values()) * 1024
+out["_summary"] = {"fetch_bytes_uncorrected": tot_r, "fetch_bytes_x2_wide_streaming_correction": 2 * tot_r, "write_bytes": tot_w,
+                   "algorithmic_bytes": 64 * 1048577, "sum_kernel_us": sum(v["kernel_us_profiled"] for k, v in out.items() if k != "_summary"),
+                   "note": "coalesced 16-byte-per-lane streaming reads: FETCH_SIZE reports half the bytes on gfx950 "
+                           "(MI355X_MICROARCH.md, HBM section); the coefficients are read twice (chunk pass and replay), "
+                           "the second time largely from L2 / Infinity Cache"}
+print(json.dumps(out, indent=1))
+open("gpurun_out/r02_quotient_pmc.json", "w").write(json.dumps(out, indent=1))
+PY
