@@ -248,6 +248,74 @@ static __device__ __noinline__ void xyzz30_add_call(XYZZ30* acc, const XYZZ30* b
 }
 #endif
 
+// ---- the general addition spread over the four lanes of a quad ---------------------------------------------------
+// The finalisation and reduction kernels are bound by chains of DEPENDENT additions, and a wave issues one
+// instruction every ~4 cycles however many of its lanes work: a lone wave needs ~15 us for the 6650 instructions of one
+// general addition (measured: 10.0 us for a mixed one, tools/microbench).  Here the four lanes of a quad hold the SAME
+// operands and each computes ONE of the (up to) four independent products of a stage; results travel by DPP quad
+// broadcasts (full-rate VALU moves).  Four stages of one product each instead of fourteen products in a row:
+//   1  U1 = X1 ZZ2       U2 = X2 ZZ1      S1 = Y1 ZZZ2      S2 = Y2 ZZZ1        -> P = U2 - U1, R = S2 - S1
+//   2  PP = P P          RR = R R         ZA = ZZ1 ZZ2      ZB = ZZZ1 ZZZ2
+//   3  PPP = P PP        Q = U1 PP        ZZ3 = ZA PP       (lane 3 repeats lane 0)   -> X3 = RR - PPP - 2Q
+//   4  ZZZ3 = ZB PPP     T1 = S1 PPP      T2 = R (Q - X3)   (lane 3 repeats lane 0)   -> Y3 = T2 - T1
+// Every lane of the quad ends with the same result; all branches (infinity, equal or opposite operands) are taken by
+// the whole quad.  Call with all four lanes of every participating quad active.
+#if defined(__HIPCC__)
+__device__ __forceinline__ Fq fq_quad_select(uint32_t q, const Fq& a0, const Fq& a1, const Fq& a2, const Fq& a3) {
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < kQ; i++) {
+        const int32_t lo = (q & 1u) ? a1.d[i] : a0.d[i];
+        const int32_t hi = (q & 1u) ? a3.d[i] : a2.d[i];
+        r.d[i] = (q & 2u) ? hi : lo;
+    }
+    return r;
+}
+template <int SRC>
+__device__ __forceinline__ Fq fq_quad_broadcast(const Fq& v) {  // lane SRC of every quad -> all four lanes
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < kQ; i++) {
+        r.d[i] = __builtin_amdgcn_mov_dpp(v.d[i], SRC * 0x55, 0xf, 0xf, true);  // quad_perm:[SRC x4]
+        // The result stays a plain v_mov_b32_dpp: when LLVM's DPP combiner (ROCm 7.2) folds the move into the
+        // subtraction that consumes it (v_subrev_u32_dpp) the lanes of a quad end up with different differences
+        // (measured on gfx950: tools/microbench quad; correct with -mllvm -amdgpu-dpp-combine=0).
+        asm volatile("" : "+v"(r.d[i]));
+    }
+    return r;
+}
+__device__ __forceinline__ void xyzz30_add_quad(XYZZ30& acc, const XYZZ30& b, uint32_t q /* lane & 3 */) {
+    if (xyzz30_is_inf(b)) return;
+    if (xyzz30_is_inf(acc)) {
+        acc = b;
+        return;
+    }
+    // stage 1
+    Fq t = fq_mul(fq_quad_select(q, acc.X, b.X, acc.Y, b.Y), fq_quad_select(q, b.ZZ, acc.ZZ, b.ZZZ, acc.ZZZ));
+    const Fq U1 = fq_quad_broadcast<0>(t), U2 = fq_quad_broadcast<1>(t), S1 = fq_quad_broadcast<2>(t), S2 = fq_quad_broadcast<3>(t);
+    const Fq P = fq_norm(fq_sub_raw(U2, U1)), R = fq_norm(fq_sub_raw(S2, S1));
+    if (fq_is_zero(P)) {
+        if (fq_is_zero(R)) xyzz30_dbl_inplace(acc);  // every lane doubles its copy
+        else acc = xyzz30_inf();
+        return;
+    }
+    // stage 2
+    t = fq_mul(fq_quad_select(q, P, R, acc.ZZ, acc.ZZZ), fq_quad_select(q, P, R, b.ZZ, b.ZZZ));
+    const Fq PP = fq_quad_broadcast<0>(t), RR = fq_quad_broadcast<1>(t), ZA = fq_quad_broadcast<2>(t), ZB = fq_quad_broadcast<3>(t);
+    // stage 3
+    t = fq_mul(fq_quad_select(q, P, U1, ZA, P), PP);
+    const Fq PPP = fq_quad_broadcast<0>(t), Q = fq_quad_broadcast<1>(t);
+    acc.ZZ = fq_quad_broadcast<2>(t);
+    const Fq X3 = fq_norm_wide(fq_sub_raw(fq_sub_raw(RR, PPP), fq_add_raw(Q, Q)));
+    // stage 4
+    const Fq QX = fq_norm(fq_sub_raw(Q, X3));
+    t = fq_mul(fq_quad_select(q, ZB, S1, R, ZB), fq_quad_select(q, PPP, PPP, QX, PPP));
+    acc.ZZZ = fq_quad_broadcast<0>(t);
+    acc.Y = fq_norm(fq_sub_raw(fq_quad_broadcast<2>(t), fq_quad_broadcast<1>(t)));
+    acc.X = X3;
+}
+#endif
+
 // XYZZ record in HBM (engine.h kXyzzBytes = 256): coordinate c (X, Y, ZZ, ZZZ) in words 16 c .. 16 c + 12
 #ifdef __HIPCC__
 __device__ __forceinline__ Fq load_fq16(const uint4* __restrict__ p) {

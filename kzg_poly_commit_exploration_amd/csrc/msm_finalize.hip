@@ -14,34 +14,25 @@
 // wait for register space next to the other slots' accumulation kernels, whether or not it finds work.
 // Inline doubling in the (rare) equal-operands branch: keeps these kernels free of scratch memory.
 
-// The general addition is inlined with its independent products interleaved (no scheduling barriers): lowest latency
-// for a lone wave, 300-450 VGPRs, one wave per SIMD -- these kernels are bound by the chain of dependent additions.
-// KZG_TREE_CALLS (A/B) makes it one call per addition instead (256 VGPRs): measured 3.5 % fewer commitments/s at
-// 2^20 and 4-7 % more latency at degree 100 ... 2500.
-#ifndef KZG_TREE_CALLS
-#define KZG_TREE_INLINE 1
-#endif
-#ifdef KZG_TREE_INLINE
+// Every addition here is spread over the four lanes of a quad (xyzz30_add_quad, g1_30.hip.h): these kernels are bound
+// by chains of dependent additions, and four stages of one product each finish a general addition 2.5 x sooner than
+// one lane's fourteen products in a row.  A "lane" below is therefore a LOGICAL lane = one quad; q = threadIdx.x & 3
+// is the position inside it; loads are issued by all four lanes (same address: one request), stores, atomics and LDS
+// writes by lane 0 of the quad.  No scheduling barriers between the products (one wave per SIMD, registers to spare).
 #define KZG_G1_30_NO_SB 1
-#define KZG_G1_30_INLINE_DBL 1
-#endif
 #include "engine.h"
 #include "g1_30.hip.h"
 
 namespace kzg {
 
-#ifdef KZG_TREE_INLINE
-#define KZG_TREE_ADD(a, b) xyzz30_add(a, b)
+constexpr int kCoop = 4;  // physical lanes per logical lane
+#define KZG_TREE_ADD(a, b) xyzz30_add_quad(a, b, threadIdx.x & 3u)
 #define KZG_TREE_WAVES 1
-#else
-#define KZG_TREE_ADD(a, b) xyzz30_add_call(&(a), &(b))
-#define KZG_TREE_WAVES 2
-#endif
 
 constexpr uint32_t kSerialSpan = 16;  // buckets spanning more segments than this go through the tree kernel
 constexpr uint32_t kSerialSpanFew = 4, kFewBuckets = 2048;  // threshold when there are at most kFewBuckets buckets
 constexpr int kChunk = 64;           // pieces per tree = lanes per workgroup of the tree passes
-constexpr int kTreeGrid = 1024;      // workgroups per tree pass (grid-stride over the work items): one resident round at one wave per SIMD
+constexpr int kTreeGrid = 256;       // workgroups per tree pass (grid-stride over the work items): one resident round (256 lanes = one wave per SIMD)
 
 // one registered long bucket
 struct HeavyEntry {
@@ -84,13 +75,14 @@ static HeavyWs carve(void* base) {
 }
 
 // One lane per bucket: short runs are added here, long ones registered for the tree passes.
-__global__ void __launch_bounds__(64, KZG_TREE_WAVES) k_bucket_finalize(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t lanes,
+__global__ void __launch_bounds__(64 * kCoop, KZG_TREE_WAVES) k_bucket_finalize(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t lanes,
                                                         const uint4* __restrict__ part_a,
                                                         const uint4* __restrict__ part_b,
                                                         uint4* __restrict__ buckets, HeavyWs ws,
                                                         uint32_t* __restrict__ refs_out) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0 && refs_out) refs_out[0] = offs[nb];  // number of references, for the host's statistics
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / kCoop;  // one quad per bucket
+    const bool lead = (threadIdx.x & 3u) == 0;
+    if (b == 0 && lead && refs_out) refs_out[0] = offs[nb];  // number of references, for the host's statistics
     if (b >= nb) return;
     const uint32_t L = accumulate_seg_len(offs[nb], lanes);
     uint32_t s = offs[b], e = offs[b + 1];
@@ -103,6 +95,7 @@ __global__ void __launch_bounds__(64, KZG_TREE_WAVES) k_bucket_finalize(const ui
     // loop 13; with many buckets the serial loops run side by side and the tree kernel would need several rounds
     const uint32_t serial_span = nb <= kFewBuckets ? kSerialSpanFew : kSerialSpan;
     if (span > serial_span) {
+        if (!lead) return;
         HeavyEntry en;
         en.bucket = b; en.l_lo = l_lo; en.span = span; en.first_is_b = first_is_b ? 1u : 0u;
         en.c1 = (span + kChunk - 1) / kChunk;
@@ -122,17 +115,18 @@ __global__ void __launch_bounds__(64, KZG_TREE_WAVES) k_bucket_finalize(const ui
         XYZZ30 p = load_xyzz30(part_a + (size_t)l * kXyzzU4);
         KZG_TREE_ADD(acc, p);
     }
-    store_xyzz30(buckets + (size_t)b * kXyzzU4, acc);
+    if (lead) store_xyzz30(buckets + (size_t)b * kXyzzU4, acc);
 }
 
 // sum of the `count` (<= 64, workgroup-uniform) accumulators held by lanes 0..count-1; result in lane 0
 __device__ __forceinline__ void tree64(XYZZ30& acc, uint32_t count, uint32_t* lds /* 52 * 64 words */) {
-    const int t = threadIdx.x;
+    const int t = threadIdx.x / kCoop;  // logical lane
+    const bool lead = (threadIdx.x & 3u) == 0;
     int top = 1;
     while (top < (int)count && top < kChunk) top <<= 1;
     for (int off = top >> 1; off >= 1; off >>= 1) {
         __syncthreads();
-        if (t >= off && t < 2 * off) {
+        if (lead && t >= off && t < 2 * off) {
             const Fq* f[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -155,12 +149,13 @@ __device__ __forceinline__ void tree64(XYZZ30& acc, uint32_t count, uint32_t* ld
 // Work items: the chunks of 64 pieces of every registered bucket.  The last workgroup to finish a chunk of a
 // group folds the group, the last to finish a group of an entry folds the entry (release: result stored, fence,
 // counter incremented; acquire: counter seen complete, fence, results loaded).
-__global__ void __launch_bounds__(kChunk, KZG_TREE_WAVES) k_heavy_tree(const uint4* __restrict__ part_a,
+__global__ void __launch_bounds__(kChunk * kCoop, KZG_TREE_WAVES) k_heavy_tree(const uint4* __restrict__ part_a,
                                                        const uint4* __restrict__ part_b,
                                                        uint4* __restrict__ buckets, HeavyWs ws) {
     __shared__ uint32_t lds[4 * kQ * kChunk];
     __shared__ uint32_t s_last;
-    const uint32_t t = threadIdx.x;
+    const uint32_t t = threadIdx.x / kCoop;             // logical lane
+    const bool lead = (threadIdx.x & 3u) == 0;
     const uint32_t total = ws.counters[1];
     for (uint32_t item = blockIdx.x; item < total; item += gridDim.x) {
         __syncthreads();  // s_last / lds of the previous item are no longer read
@@ -179,13 +174,13 @@ __global__ void __launch_bounds__(kChunk, KZG_TREE_WAVES) k_heavy_tree(const uin
         }
         tree64(acc, count, lds);
         if (en.c1 == 1) {
-            if (t == 0) store_xyzz30(bucket, acc);
+            if (t == 0 && lead) store_xyzz30(bucket, acc);
             continue;
         }
         // level 2: the chunk results of group g, by whoever completes it
         const uint32_t g = j / kChunk;
         const uint32_t in_group = en.c1 - g * kChunk < (uint32_t)kChunk ? en.c1 - g * kChunk : (uint32_t)kChunk;
-        if (t == 0) {
+        if (t == 0 && lead) {
             store_xyzz30(ws.tmp1 + (size_t)item * kXyzzU4, acc);
             __threadfence();
             s_last = atomicAdd(&ws.group_done[en.base2 + g], 1u) == in_group - 1 ? 1u : 0u;
@@ -197,12 +192,12 @@ __global__ void __launch_bounds__(kChunk, KZG_TREE_WAVES) k_heavy_tree(const uin
         if (t < in_group) acc = load_xyzz30(ws.tmp1 + (size_t)(en.base1 + g * kChunk + t) * kXyzzU4);
         tree64(acc, in_group, lds);
         if (en.c2 == 1) {
-            if (t == 0) store_xyzz30(bucket, acc);
+            if (t == 0 && lead) store_xyzz30(bucket, acc);
             continue;
         }
         // level 3: the group results of the entry
         __syncthreads();
-        if (t == 0) {
+        if (t == 0 && lead) {
             store_xyzz30(ws.tmp2 + (size_t)(en.base2 + g) * kXyzzU4, acc);
             __threadfence();
             s_last = atomicAdd(&ws.entry_done[slot], 1u) == en.c2 - 1 ? 1u : 0u;
@@ -216,7 +211,7 @@ __global__ void __launch_bounds__(kChunk, KZG_TREE_WAVES) k_heavy_tree(const uin
             KZG_TREE_ADD(acc, p);
         }
         tree64(acc, en.c2 < (uint32_t)kChunk ? en.c2 : (uint32_t)kChunk, lds);
-        if (t == 0) store_xyzz30(bucket, acc);
+        if (t == 0 && lead) store_xyzz30(bucket, acc);
     }
 }
 
@@ -226,8 +221,8 @@ void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, 
     const uint4* pa = reinterpret_cast<const uint4*>(d_part_a);
     const uint4* pb = reinterpret_cast<const uint4*>(d_part_b);
     uint4* bk = reinterpret_cast<uint4*>(d_buckets);
-    hipLaunchKernelGGL(k_bucket_finalize, dim3((nb + 63) / 64), dim3(64), 0, s, d_offs, nb, lanes, pa, pb, bk, ws, d_refs_out);
-    hipLaunchKernelGGL(k_heavy_tree, dim3(kTreeGrid), dim3(kChunk), 0, s, pa, pb, bk, ws);
+    hipLaunchKernelGGL(k_bucket_finalize, dim3((nb + 63) / 64), dim3(64 * kCoop), 0, s, d_offs, nb, lanes, pa, pb, bk, ws, d_refs_out);
+    hipLaunchKernelGGL(k_heavy_tree, dim3(kTreeGrid), dim3(kChunk * kCoop), 0, s, pa, pb, bk, ws);
 }
 
 }  // namespace kzg

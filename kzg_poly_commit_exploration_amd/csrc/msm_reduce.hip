@@ -15,29 +15,17 @@
 // addition 40 % (2.8 vs 1.6 G additions/s, gpurun_out microbench), the register traffic around the
 // calls outweighing the instruction-cache savings.
 
-// The general addition is inlined with its independent products interleaved (no scheduling barriers): lowest latency
-// for a lone wave, 300-450 VGPRs, one wave per SIMD -- these kernels are bound by the chain of dependent additions.
-// KZG_TREE_CALLS (A/B) makes it one call per addition instead (256 VGPRs): measured 3.5 % fewer commitments/s at
-// 2^20 and 4-7 % more latency at degree 100 ... 2500.
-#ifndef KZG_TREE_CALLS
-#define KZG_TREE_INLINE 1
-#endif
-#ifdef KZG_TREE_INLINE
+// Every addition is spread over the four lanes of a quad (xyzz30_add_quad, g1_30.hip.h; see msm_finalize.hip): a lane
+// below is a LOGICAL lane = one quad of the 256-thread workgroup (64 logical lanes).
 #define KZG_G1_30_NO_SB 1
-#define KZG_G1_30_INLINE_DBL 1
-#endif
 #include "engine.h"
 #include "g1_30.hip.h"
 
 namespace kzg {
 
-#ifdef KZG_TREE_INLINE
-#define KZG_TREE_ADD(a, b) xyzz30_add(a, b)
+constexpr int kCoop = 4;  // physical lanes per logical lane
+#define KZG_TREE_ADD(a, b) xyzz30_add_quad(a, b, threadIdx.x & 3u)
 #define KZG_TREE_WAVES 1
-#else
-#define KZG_TREE_ADD(a, b) xyzz30_add_call(&(a), &(b))
-#define KZG_TREE_WAVES 2
-#endif
 
 constexpr int kTreeBlock = 256;
 
@@ -57,15 +45,17 @@ struct TreeJobs {
 };
 
 __global__ void __launch_bounds__(kTreeBlock, KZG_TREE_WAVES) k_tree_sum(TreeJobs jobs) {
-    __shared__ uint32_t lds[4 * kQ * kTreeBlock];
-    const int t = threadIdx.x;
+    constexpr int kLogical = kTreeBlock / kCoop;  // logical lanes per workgroup
+    __shared__ uint32_t lds[4 * kQ * kLogical];
+    const int t = threadIdx.x / kCoop;
+    const bool lead = (threadIdx.x & 3u) == 0;
     uint32_t ji = 0;
 #pragma unroll
     for (uint32_t q = 1; q < 4; q++)
         if (q < jobs.count && blockIdx.x >= jobs.j[q].first_block) ji = q;
     const TreeJob J = jobs.j[ji];
     const uint32_t lanes_per_group = J.lanes_per_group;
-    const uint32_t gpb = kTreeBlock / lanes_per_group;
+    const uint32_t gpb = kLogical / lanes_per_group;
     const uint32_t g = (blockIdx.x - J.first_block) * gpb + t / lanes_per_group;
     const uint32_t l = t & (lanes_per_group - 1);
     XYZZ30 acc = xyzz30_inf();
@@ -78,12 +68,12 @@ __global__ void __launch_bounds__(kTreeBlock, KZG_TREE_WAVES) k_tree_sum(TreeJob
     }
     for (uint32_t off = lanes_per_group >> 1; off >= 1; off >>= 1) {
         __syncthreads();
-        if (l >= off && l < 2 * off) {
+        if (lead && l >= off && l < 2 * off) {
             const Fq* f[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int i = 0; i < kQ; i++) lds[(q * kQ + i) * kTreeBlock + (t - off)] = (uint32_t)f[q]->d[i];
+                for (int i = 0; i < kQ; i++) lds[(q * kQ + i) * kLogical + (t - off)] = (uint32_t)f[q]->d[i];
         }
         __syncthreads();
         if (l < off) {
@@ -92,33 +82,32 @@ __global__ void __launch_bounds__(kTreeBlock, KZG_TREE_WAVES) k_tree_sum(TreeJob
 #pragma unroll
             for (int q = 0; q < 4; q++)
 #pragma unroll
-                for (int i = 0; i < kQ; i++) f[q]->d[i] = (int32_t)lds[(q * kQ + i) * kTreeBlock + t];
+                for (int i = 0; i < kQ; i++) f[q]->d[i] = (int32_t)lds[(q * kQ + i) * kLogical + t];
             KZG_TREE_ADD(acc, o);
         }
     }
-    if (l == 0 && g < J.groups) store_xyzz30(J.out + (size_t)g * kXyzzU4, acc);
+    if (lead && l == 0 && g < J.groups) store_xyzz30(J.out + (size_t)g * kXyzzU4, acc);
 }
 
 void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count) {
     TreeJobs jobs;
     jobs.count = count;
-    // One lane per element gives the shortest chain (log2(len) dependent additions) but only ~1/log2(len)
-    // of the lane-steps do work.  The kernel holds KZG_TREE_WAVES waves per SIMD (inlined additions: 300+ VGPRs, one
-    // wave), i.e. KZG_TREE_WAVES workgroups of 256 lanes per CU: beyond that a second round would start, which costs a
-    // whole tree's latency -- lanes then pre-add several elements serially instead (one more dependent addition per
-    // doubling).  (Round 1 assumed three resident workgroups; with one, 131072 one-element lanes ran as two rounds:
-    // 167 us per stage-1 launch at 65536 buckets.)
+    // One (logical) lane per element gives the shortest chain (log2(len) dependent additions) but only ~1/log2(len)
+    // of the lane-steps do work.  A CU holds one workgroup (one wave per SIMD) = 64 logical lanes: beyond 256
+    // workgroups a second round would start, which costs a whole tree's latency -- lanes then pre-add several
+    // elements serially instead (one more dependent addition per doubling).
+    constexpr uint32_t kLogical = kTreeBlock / kCoop;
     uint64_t total = 0;
     for (uint32_t i = 0; i < count && i < 4; i++) total += (uint64_t)descs[i].groups * descs[i].len;
-    const uint64_t resident_lanes = (uint64_t)KZG_TREE_WAVES * 256 * kTreeBlock;
+    const uint64_t resident_lanes = (uint64_t)KZG_TREE_WAVES * 256 * kLogical;
     uint32_t per_lane = 1;
     while ((total + per_lane - 1) / per_lane > resident_lanes && per_lane < 64) per_lane <<= 1;
     uint32_t blocks = 0;
     for (uint32_t i = 0; i < count && i < 4; i++) {
         uint32_t lpg = 1;
-        while (lpg < descs[i].len && lpg < (uint32_t)kTreeBlock) lpg <<= 1;
+        while (lpg < descs[i].len && lpg < kLogical) lpg <<= 1;
         lpg = lpg / per_lane ? lpg / per_lane : 1;
-        uint32_t gpb = kTreeBlock / lpg;
+        uint32_t gpb = kLogical / lpg;
         jobs.j[i].in = reinterpret_cast<const uint4*>(descs[i].in);
         jobs.j[i].out = reinterpret_cast<uint4*>(descs[i].out);
         jobs.j[i].groups = descs[i].groups;

@@ -320,6 +320,102 @@ __global__ void __launch_bounds__(256) k_madd30(u32* io, int iters) {
     }
     if (acc.X.d[3] == 0x12345 && acc.Y.d[2] == 77) io[80] = 1;
 }
+
+// ---- quad-cooperative general addition (xyzz30_add_quad) against the one-lane xyzz30_add -----------------------
+// Every quad builds A = (4 + tid/4) P and B = 3P, adds them both ways; quad 0 writes both results and lane q of quad 0
+// writes the stage-1 product it computed (words 128 + 13 q).
+__global__ void __launch_bounds__(256) k_addquad(u32* io, int iters, int* cmp) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = threadIdx.x & 3u;
+    Affine30 p;
+    p.x = fq_mul(fq_from_u32x12(io), fq_one());
+    p.y = fq_mul(fq_from_u32x12(io + 12), fq_one());
+    XYZZ30 a = xyzz30_inf(), b = xyzz30_inf();
+    xyzz30_madd(a, p, false);
+    xyzz30_madd(a, p, false);
+    xyzz30_dbl_inplace(a);  // 4P
+    for (int k = 0; k < (tid / 4) % 5; k++) xyzz30_madd(a, p, false);
+    xyzz30_madd(b, p, false);
+    xyzz30_madd(b, p, false);
+    xyzz30_madd(b, p, false);  // 3P
+    XYZZ30 r1 = a, r2 = a;
+    for (int it = 0; it < iters; it++) {
+        xyzz30_add(r1, b);
+        xyzz30_add_quad(r2, b, q);
+    }
+    // projective equality r1 == r2: X1 ZZ2 == X2 ZZ1, Y1 ZZZ2 == Y2 ZZZ1
+    const bool same = fq_is_zero(fq_norm(fq_sub_raw(fq_mul(r1.X, r2.ZZ), fq_mul(r2.X, r1.ZZ)))) &&
+                      fq_is_zero(fq_norm(fq_sub_raw(fq_mul(r1.Y, r2.ZZZ), fq_mul(r2.Y, r1.ZZZ))));
+    if (!same) atomicAdd(cmp, 1);
+    bool digits = true;
+    for (int i = 0; i < kQ; i++) digits = digits && r1.X.d[i] == r2.X.d[i] && r1.Y.d[i] == r2.Y.d[i] && r1.ZZ.d[i] == r2.ZZ.d[i] && r1.ZZZ.d[i] == r2.ZZZ.d[i];
+    if (!digits) atomicAdd(cmp + 1, 1);
+    if (tid < 16) {
+        int m = 0;
+        bool e;
+        e = true; for (int i = 0; i < kQ; i++) e = e && r1.X.d[i] == r2.X.d[i]; m |= e ? 1 : 0;
+        e = true; for (int i = 0; i < kQ; i++) e = e && r1.Y.d[i] == r2.Y.d[i]; m |= e ? 2 : 0;
+        e = true; for (int i = 0; i < kQ; i++) e = e && r1.ZZ.d[i] == r2.ZZ.d[i]; m |= e ? 4 : 0;
+        e = true; for (int i = 0; i < kQ; i++) e = e && r1.ZZZ.d[i] == r2.ZZZ.d[i]; m |= e ? 8 : 0;
+        cmp[8 + tid] = m;
+        cmp[32 + tid] = r2.Y.d[0];
+        cmp[48 + tid] = r2.Y.d[12];
+        cmp[64 + tid] = r1.Y.d[0];
+        cmp[80 + tid] = r1.Y.d[12];
+    }
+    if (tid == 0) {
+        fq_to_u32x12(r1.X, io + 24);
+        fq_to_u32x12(r1.Y, io + 36);
+        fq_to_u32x12(r2.X, io + 48);
+        fq_to_u32x12(r2.Y, io + 60);
+    }
+}
+
+__device__ __forceinline__ void add_quad_dbg(XYZZ30& acc, const XYZZ30& b, uint32_t q, int* tap) {
+    Fq t = fq_mul(fq_quad_select(q, acc.X, b.X, acc.Y, b.Y), fq_quad_select(q, b.ZZ, acc.ZZ, b.ZZZ, acc.ZZZ));
+    const Fq U1 = fq_quad_broadcast<0>(t), U2 = fq_quad_broadcast<1>(t), S1 = fq_quad_broadcast<2>(t), S2 = fq_quad_broadcast<3>(t);
+    const Fq P = fq_norm(fq_sub_raw(U2, U1)), R = fq_norm(fq_sub_raw(S2, S1));
+    t = fq_mul(fq_quad_select(q, P, R, acc.ZZ, acc.ZZZ), fq_quad_select(q, P, R, b.ZZ, b.ZZZ));
+    const Fq PP = fq_quad_broadcast<0>(t), RR = fq_quad_broadcast<1>(t), ZA = fq_quad_broadcast<2>(t), ZB = fq_quad_broadcast<3>(t);
+    t = fq_mul(fq_quad_select(q, P, U1, ZA, P), PP);
+    const Fq PPP = fq_quad_broadcast<0>(t), Q = fq_quad_broadcast<1>(t);
+    acc.ZZ = fq_quad_broadcast<2>(t);
+    const Fq X3 = fq_norm_wide(fq_sub_raw(fq_sub_raw(RR, PPP), fq_add_raw(Q, Q)));
+    const Fq QX = fq_norm(fq_sub_raw(Q, X3));
+    const Fq sa = fq_quad_select(q, ZB, S1, R, ZB), sb = fq_quad_select(q, PPP, PPP, QX, PPP);
+    t = fq_mul(sa, sb);
+    const Fq b0 = fq_quad_broadcast<0>(t), b1 = fq_quad_broadcast<1>(t), b2 = fq_quad_broadcast<2>(t);
+    tap[threadIdx.x * 8 + 0] = t.d[0];
+    tap[threadIdx.x * 8 + 1] = b0.d[0];
+    tap[threadIdx.x * 8 + 2] = b1.d[0];
+    tap[threadIdx.x * 8 + 3] = b2.d[0];
+    tap[threadIdx.x * 8 + 4] = sa.d[0];
+    tap[threadIdx.x * 8 + 5] = sb.d[0];
+    tap[threadIdx.x * 8 + 6] = S1.d[0];
+    tap[threadIdx.x * 8 + 7] = R.d[0];
+    acc.ZZZ = b0;
+    acc.Y = fq_norm(fq_sub_raw(b2, b1));
+    acc.X = X3;
+}
+__global__ void __launch_bounds__(64) k_addquad_dbg(u32* io, int* tap) {
+    const uint32_t q = threadIdx.x & 3u;
+    Affine30 p;
+    p.x = fq_mul(fq_from_u32x12(io), fq_one());
+    p.y = fq_mul(fq_from_u32x12(io + 12), fq_one());
+    XYZZ30 a = xyzz30_inf(), b = xyzz30_inf();
+    xyzz30_madd(a, p, false);
+    xyzz30_madd(a, p, false);
+    xyzz30_dbl_inplace(a);  // 4P
+    xyzz30_madd(b, p, false);
+    xyzz30_madd(b, p, false);
+    xyzz30_madd(b, p, false);  // 3P
+    add_quad_dbg(a, b, q, tap);
+    tap[512 + threadIdx.x] = a.Y.d[0];
+}
+__global__ void __launch_bounds__(256) k_dpp_probe(int* out) {
+    const int v = threadIdx.x * 10;
+    out[threadIdx.x] = __builtin_amdgcn_mov_dpp(v, 2 * 0x55, 0xf, 0xf, true);
+}
 // instruction mix of an fp64-FMA multiplier (Emmart et al.: 52-bit limbs, 8 limbs for 381 bits): per limb product
 // two v_fma_f64 (high and low half), one v_add_f64 (the correction term) and two 64-bit integer adds; 128 limb
 // products per Montgomery product.  NOT a multiplier -- the dependency shape and the instruction counts only.
@@ -680,7 +776,53 @@ static int run_field30() {
     return 0;
 }
 
+
+static int run_quad() {
+    const u32 GX[12] = {0xfd530c16u, 0x5cb38790u, 0x9976fff5u, 0x7817fc67u, 0x143ba1c1u, 0x154f95c7u,
+                        0xf3d0e747u, 0xf0ae6acdu, 0x21dbf440u, 0xedce6eccu, 0x9e0bfb75u, 0x12017741u};
+    const u32 GY[12] = {0x0ce72271u, 0xbaac93d5u, 0x7918fd8eu, 0x8c22631au, 0x570725ceu, 0xdd595f13u,
+                        0x50405194u, 0x51ac5829u, 0xad0059c0u, 0x0e1c8c3fu, 0x5008a26au, 0x0bbc3efcu};
+    u32 hin[256];
+    memset(hin, 0, sizeof hin);
+    memcpy(hin, GX, 48);
+    memcpy(hin + 12, GY, 48);
+    u32* dio;
+    int* cmp;
+    CHECK(hipMalloc(&dio, sizeof hin));
+    CHECK(hipMalloc(&cmp, 1024));
+    int hc[256];
+    CHECK(hipMemset(cmp, 0, 1024));
+    hipLaunchKernelGGL(k_dpp_probe, dim3(1), dim3(64), 0, 0, cmp);
+    CHECK(hipMemcpy(hc, cmp, 256, hipMemcpyDeviceToHost));
+    printf("{\"probe\": \"dpp_quad_broadcast_lane2\", \"first8\": [%d, %d, %d, %d, %d, %d, %d, %d]}\n", hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7]);
+    {
+        int* tap;
+        int ht[1024];
+        CHECK(hipMalloc(&tap, sizeof ht));
+        CHECK(hipMemset(tap, 0, sizeof ht));
+        CHECK(hipMemcpy(dio, hin, sizeof hin, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_addquad_dbg, dim3(1), dim3(64), 0, 0, dio, tap);
+        CHECK(hipMemcpy(ht, tap, sizeof ht, hipMemcpyDeviceToHost));
+        for (int l = 0; l < 8; l++)
+            printf("  dbg lane %d t %d b0 %d b1 %d b2 %d sa %d sb %d S1 %d R %d Y %d\n", l, ht[l * 8], ht[l * 8 + 1], ht[l * 8 + 2], ht[l * 8 + 3], ht[l * 8 + 4], ht[l * 8 + 5], ht[l * 8 + 6], ht[l * 8 + 7], ht[512 + l]);
+    }
+    for (int iters = 1; iters <= 4; iters++) {
+        CHECK(hipMemcpy(dio, hin, sizeof hin, hipMemcpyHostToDevice));
+        CHECK(hipMemset(cmp, 0, 1024));
+        hipLaunchKernelGGL(k_addquad, dim3(2), dim3(256), 0, 0, dio, iters, cmp);
+        CHECK(hipMemcpy(hc, cmp, 96 * 4, hipMemcpyDeviceToHost));
+        printf("{\"probe\": \"add_quad_vs_add\", \"iters\": %d, \"lanes_point_differs\": %d, \"lanes_digits_differ\": %d}\n", iters, hc[0], hc[1]);
+        for (int k = 0; k < 16; k++) printf("  lane %d mask %x quadY0 %d quadY12 %d refY0 %d refY12 %d\n", k, hc[8 + k], hc[32 + k], hc[48 + k], hc[64 + k], hc[80 + k]);
+    }
+    for (int it = 0; it < 2; it++) {
+        CHECK(hipMemcpy(dio, hin, sizeof hin, hipMemcpyHostToDevice));
+        double ms = time_kernel(k_addquad, 1, 64, 5, dio, 64, cmp);
+        printf("{\"bench\": \"lone_wave_add_plus_add_quad\", \"us_per_pair\": %.3f}\n", ms * 1e3 / 64.0);
+    }
+    return 0;
+}
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "quad")) return run_quad();
     if (argc > 1 && !strcmp(argv[1], "field30")) return run_field30();
     if (argc > 1 && !strcmp(argv[1], "carrydbg")) return run_carry_debug();
     if (argc > 1 && !strcmp(argv[1], "carry")) return run_carry();
