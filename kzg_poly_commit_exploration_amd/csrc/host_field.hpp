@@ -11,6 +11,8 @@
 #include <cstring>
 #include <initializer_list>
 
+#include "field30_inv.hip.h"
+
 namespace kzg_host {
 
 typedef unsigned __int128 u128;
@@ -69,8 +71,9 @@ inline Fp neg(const Fp& a) {
     return a.is_zero() ? a : raw_sub(kP, a, br);
 }
 // Montgomery product a * b / 2^384 mod p, coarsely integrated operand scanning (CIOS), fully unrolled by the
-// compiler.  Accepts any a < 2^384 and b < p (the result of an unreduced addition may enter as a).
-inline Fp operator*(const Fp& a, const Fp& b) {
+// compiler.  Accepts any a < 2^384 and b < p (the result of an unreduced addition may enter as a): used where an
+// operand is not reduced (fp_from_digits30); operator* below is the product of two reduced elements.
+inline Fp mul_wide(const Fp& a, const Fp& b) {
     uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < 6; ++i) {
         u128 c = 0;
@@ -98,8 +101,39 @@ inline Fp operator*(const Fp& a, const Fp& b) {
     if (t[6] || geq(r, kP)) r = raw_sub(r, kP, br);
     return r;
 }
+// a, b < p.  p < 2^383 leaves the top bit of every partial sum free, so the two carry words of the general routine
+// disappear (the "no-carry" CIOS): each round is two interleaved multiply-accumulate chains over six limbs.
+inline Fp operator*(const Fp& a, const Fp& b) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    for (int i = 0; i < 6; ++i) {
+        const uint64_t bi = b.l[i];
+        u128 A = (u128)a.l[0] * bi + t0;
+        const uint64_t m = (uint64_t)A * kN0;
+        u128 C = (u128)m * kP.l[0] + (uint64_t)A;
+        A = (u128)a.l[1] * bi + t1 + (uint64_t)(A >> 64);
+        C = (u128)m * kP.l[1] + (uint64_t)A + (uint64_t)(C >> 64);
+        t0 = (uint64_t)C;
+        A = (u128)a.l[2] * bi + t2 + (uint64_t)(A >> 64);
+        C = (u128)m * kP.l[2] + (uint64_t)A + (uint64_t)(C >> 64);
+        t1 = (uint64_t)C;
+        A = (u128)a.l[3] * bi + t3 + (uint64_t)(A >> 64);
+        C = (u128)m * kP.l[3] + (uint64_t)A + (uint64_t)(C >> 64);
+        t2 = (uint64_t)C;
+        A = (u128)a.l[4] * bi + t4 + (uint64_t)(A >> 64);
+        C = (u128)m * kP.l[4] + (uint64_t)A + (uint64_t)(C >> 64);
+        t3 = (uint64_t)C;
+        A = (u128)a.l[5] * bi + t5 + (uint64_t)(A >> 64);
+        C = (u128)m * kP.l[5] + (uint64_t)A + (uint64_t)(C >> 64);
+        t4 = (uint64_t)C;
+        t5 = (uint64_t)(C >> 64) + (uint64_t)(A >> 64);
+    }
+    const Fp r = {{t0, t1, t2, t3, t4, t5}};
+    uint64_t br;
+    const Fp s = raw_sub(r, kP, br);
+    return br ? r : s;
+}
 inline Fp sqr(const Fp& a) { return a * a; }
-inline Fp inv(const Fp& a) {  // a^(p-2)
+inline Fp inv_fermat(const Fp& a) {  // a^(p-2): ~570 products; kept as the cross-check of inv() in tests/host
     Fp e = kP;
     e.l[0] -= 2;
     Fp acc = kOne, base = a;
@@ -108,6 +142,19 @@ inline Fp inv(const Fp& a) {  // a^(p-2)
         base = sqr(base);
     }
     return acc;
+}
+// Inverse by the same division-step routine the device uses (field30_inv.hip.h, host-compiled): the twelve 32-bit
+// words of a Montgomery-form element are exactly what fq_from_u32x12 / fq_to_u32x12 exchange.  About a sixth of the
+// cost of the Fermat power; it sits on the latency path of every commitment (p1_normalize of the final sum).
+inline Fp inv(const Fp& a) {
+    if (a.is_zero()) return a;
+    uint32_t w[12];
+    std::memcpy(w, a.l, sizeof w);
+    const kzg::Fq r = kzg::fq_inv(kzg::fq_from_u32x12(w));
+    kzg::fq_to_u32x12(r, w);
+    Fp out;
+    std::memcpy(out.l, w, sizeof w);
+    return out;
 }
 inline Fp from_mont(const Fp& a) {
     Fp one = {{1, 0, 0, 0, 0, 0}};
@@ -197,7 +244,7 @@ inline Fp fp_from_digits30(const int32_t d[13]) {
     Fp v;
     for (int k = 0; k < 6; ++k) v.l[k] = w[k];  // w[6] == 0 by the magnitude bound
     static const Fp k2_378 = {{0, 0, 0, 0, 0, 0x0400000000000000ULL}};
-    return v * k2_378;
+    return mul_wide(v, k2_378);
 }
 // device XYZZ partial sum (256-byte record: X, Y, ZZ, ZZZ digits at 64-byte steps) -> Jacobian with Z = ZZ:
 // X*ZZ, Y*ZZZ, ZZ

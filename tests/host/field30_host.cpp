@@ -6,6 +6,7 @@
 
 #include "../../kzg_poly_commit_exploration_amd/csrc/field30_inv.hip.h"
 #include "../../kzg_poly_commit_exploration_amd/csrc/g1_30.hip.h"
+#include "../../kzg_poly_commit_exploration_amd/csrc/host_field.hpp"
 
 using namespace kzg;
 
@@ -186,5 +187,32 @@ int64_t f30_mul_max_column(const int32_t* a, const int32_t* b) {
         acc = (acc - dgt) >> 30;
     }
     return (int64_t)(worst >> 48);
+}
+
+// ---- the library's host field (csrc/host_field.hpp: 6 x u64, Montgomery R = 2^384) ----
+void hf_mul(const uint64_t* a, const uint64_t* b, uint64_t* r) {
+    kzg_host::Fp x, y;
+    memcpy(x.l, a, 48);
+    memcpy(y.l, b, 48);
+    const kzg_host::Fp z = x * y;
+    memcpy(r, z.l, 48);
+}
+void hf_mul_wide(const uint64_t* a, const uint64_t* b, uint64_t* r) {
+    kzg_host::Fp x, y;
+    memcpy(x.l, a, 48);
+    memcpy(y.l, b, 48);
+    const kzg_host::Fp z = kzg_host::mul_wide(x, y);
+    memcpy(r, z.l, 48);
+}
+void hf_inv(const uint64_t* a, uint64_t* r, uint64_t* r_fermat) {
+    kzg_host::Fp x;
+    memcpy(x.l, a, 48);
+    const kzg_host::Fp z = kzg_host::inv(x), w = kzg_host::inv_fermat(x);
+    memcpy(r, z.l, 48);
+    memcpy(r_fermat, w.l, 48);
+}
+void hf_from_digits30(const int32_t* d, uint64_t* r) {
+    const kzg_host::Fp z = kzg_host::fp_from_digits30(d);
+    memcpy(r, z.l, 48);
 }
 }

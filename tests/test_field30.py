@@ -358,3 +358,46 @@ def test_group_law_general_addition(lib):
         b, wb = build(kb)
         lib.f30_add(a, b)
         assert affine_of(a) == _ec_add(wa, wb), (ka, kb)
+
+
+U6 = ctypes.c_uint64 * 6
+
+
+def _limbs(v):
+    return U6(*[(v >> (64 * i)) & ((1 << 64) - 1) for i in range(6)])
+
+
+def _int6(a):
+    return sum(int(x) << (64 * i) for i, x in enumerate(a))
+
+
+def test_host_field_products_and_inverse(lib):
+    """csrc/host_field.hpp (the host tail of every commitment): the no-carry product of reduced elements, the general
+    product with an unreduced left operand, the division-step inverse against the Fermat power and against Python,
+    and the conversion of a device record's lazily reduced digits."""
+    rng = random.Random(4242)
+    rinv = pow(R384, -1, P)
+    edge = [0, 1, P - 1, P - 2, (P - 1) // 2, R384 % P]
+    for k in range(300):
+        a = edge[k % len(edge)] if k < 24 else rng.randrange(P)
+        b = edge[(k // len(edge)) % len(edge)] if k < 24 else rng.randrange(P)
+        r = U6()
+        lib.hf_mul(_limbs(a), _limbs(b), r)
+        assert _int6(r) == a * b * rinv % P
+        wide = rng.randrange(1 << 384)  # any 384-bit left operand
+        lib.hf_mul_wide(_limbs(wide), _limbs(b), r)
+        assert _int6(r) == wide * b * rinv % P
+    for k in range(60):
+        a = [1, P - 1, 2, R384 % P][k] if k < 4 else rng.randrange(1, P)
+        r, f = U6(), U6()
+        lib.hf_inv(_limbs(a), r, f)
+        x = a * rinv % P  # the element a represents
+        assert _int6(r) == pow(x, -1, P) * R384 % P
+        assert _int6(r) == _int6(f)
+    r, f = U6(), U6()
+    lib.hf_inv(_limbs(0), r, f)
+    assert _int6(r) == 0
+    for _ in range(100):
+        v = rng.randrange(-3 * P, 3 * P)  # |v| < 3.5 p as the kernels leave it
+        lib.hf_from_digits30(I13(*balanced(v)), r)
+        assert _int6(r) == v * pow(1 << 6, -1, P) % P
