@@ -117,6 +117,8 @@ struct kzg_ctx {
     // 170 VGPRs (a 168-VGPR build with 10 spilled registers measured 9 % slower with three slots in flight).
     uint32_t accum_lds_bytes = 41u * 1024u;
     uint32_t gate_lds_bytes = 100u * 1024u;  // k_reduce_gate (KZG_REDUCE_GATE_KB overrides, 0 disables)
+    uint32_t small_lds_bytes = 48u * 1024u;  // k_small_msm's LDS reservation (raised to small_msm_lds_bytes() at creation)
+    bool small_msm_off = false;              // KZG_SMALL_MSM=0: small jobs take the general multi-launch path (A/B, tests)
     bool slots_ready = false;
     bool timing = false;
 };
@@ -344,45 +346,53 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
     }
     bool alone = true;  // (this slot is still marked idle while its job is being enqueued)
     for (const auto& other : ctx->slots) alone = alone && (&other == &s || other.kind == SLOT_IDLE);
-    const uint32_t lanes = accumulate_lanes((uint64_t)n * cfg.max_digits * batch, alone);
-    HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)nbt * kXyzzBytes, st));  // zero = infinity
-    HIP_TRY(ctx, hipMemsetAsync(s.d_heavy_ws, 0, 32, st));                        // long-bucket counters
-    // hand over to the shared accumulation stream and back
-    hipStream_t hs = ctx->serialize_accum ? ctx->heavy_stream : st;
-    if (ctx->serialize_accum) {
-        HIP_TRY(ctx, hipEventRecord(s.sorted_ev, st));
-        HIP_TRY(ctx, hipStreamWaitEvent(hs, s.sorted_ev, 0));
-    }
-    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 3], hs));
-    launch_bucket_accumulate(hs, ctx->d_table, s.d_sorted, s.d_offs, nbt, lanes, s.d_buckets, s.d_part_a, s.d_part_b,
-                             ctx->accum_lds_bytes, s.d_pair_scratch, (uint64_t)n * cfg.max_digits * batch);
-    if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], hs));
-    if (ctx->serialize_accum) {
-        HIP_TRY(ctx, hipEventRecord(s.accum_ev, hs));
-        HIP_TRY(ctx, hipStreamWaitEvent(st, s.accum_ev, 0));
-    }
-    launch_bucket_finalize(st, s.d_offs, nbt, lanes, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_ws, s.d_small + 26);
-    // (gating the finalisation as well measured 3-5 % slower: it is short and wants to run at once)
-    if (ctx->gate_lds_bytes && !alone) hipLaunchKernelGGL(k_reduce_gate, dim3(1), dim3(64), ctx->gate_lds_bytes, st, (uint32_t*)nullptr);
+    const uint64_t max_refs = (uint64_t)n * cfg.max_digits * batch;
+    const uint32_t lanes = accumulate_lanes(max_refs, alone);
     // reduction: Row / Col tree sums of every polynomial's bucket matrix, each split once more.
     // Vectors are polynomial-major ([p][index]); the final buffer holds four sections [p][len_k].
-    {
-        const ReducePlan& P = ctx->plan;
-        const uint32_t R = 1u << P.hi_bits, C = 1u << P.lo_bits, B = batch;
-        char* row = (char*)s.d_arena;
-        char* col = row + (size_t)R * B * kXyzzBytes;
-        char* fin = (char*)s.d_final;
-        const uint32_t rl = 1u << P.row_lo, rh = 1u << P.row_hi, cl = 1u << P.col_lo, ch = 1u << P.col_hi;
-        TreeSumDesc stage1[2] = {
-            {s.d_buckets, row, B * R, C, C, 1, B * R, 0},           // Row[p][hi] = sum_lo Bk[p][hi*C + lo]
-            {s.d_buckets, col, B * C, R, 1, C, C, (uint64_t)cfg.nb}};  // Col[p][lo] = sum_hi Bk[p][hi*C + lo]
-        launch_tree_sums(st, stage1, 2);
-        TreeSumDesc stage2[4] = {
-            {row, fin + (size_t)P.off_r2row * B * kXyzzBytes, B * rh, rl, rl, 1, rh, R},
-            {row, fin + (size_t)P.off_c2row * B * kXyzzBytes, B * rl, rh, 1, rl, rl, R},
-            {col, fin + (size_t)P.off_r2col * B * kXyzzBytes, B * ch, cl, cl, 1, ch, C},
-            {col, fin + (size_t)P.off_c2col * B * kXyzzBytes, B * cl, ch, 1, cl, cl, C}};
-        launch_tree_sums(st, stage2, 4);
+    const ReducePlan& P = ctx->plan;
+    const uint32_t R = 1u << P.hi_bits, C = 1u << P.lo_bits, B = batch;
+    char* row = (char*)s.d_arena;
+    char* col = row + (size_t)R * B * kXyzzBytes;
+    char* fin = (char*)s.d_final;
+    const uint32_t rl = 1u << P.row_lo, rh = 1u << P.row_hi, cl = 1u << P.col_lo, ch = 1u << P.col_hi;
+    const TreeSumDesc stage1[2] = {
+        {s.d_buckets, row, B * R, C, C, 1, B * R, 0},           // Row[p][hi] = sum_lo Bk[p][hi*C + lo]
+        {s.d_buckets, col, B * C, R, 1, C, C, (uint64_t)cfg.nb}};  // Col[p][lo] = sum_hi Bk[p][hi*C + lo]
+    const TreeSumDesc stage2[4] = {
+        {row, fin + (size_t)P.off_r2row * B * kXyzzBytes, B * rh, rl, rl, 1, rh, R},
+        {row, fin + (size_t)P.off_c2row * B * kXyzzBytes, B * rl, rh, 1, rl, rl, R},
+        {col, fin + (size_t)P.off_r2col * B * kXyzzBytes, B * ch, cl, cl, 1, ch, C},
+        {col, fin + (size_t)P.off_c2col * B * kXyzzBytes, B * cl, ch, 1, cl, cl, C}};
+    HIP_TRY(ctx, hipMemsetAsync(s.d_heavy_ws, 0, kHeavyHeaderBytes, st));  // long-bucket counters, phase counters
+    if (max_refs <= kTinyRefs && !ctx->small_msm_off) {
+        // Small jobs are chains of dependent additions on a nearly empty chip: everything from here to the copy back
+        // in ONE launch on the slot's own stream (msm_finalize.hip: k_small_msm), no bucket memset, no stream hand-over.
+        if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 3], st));
+        launch_small_msm(st, ctx->d_table, s.d_sorted, s.d_offs, nbt, lanes, s.d_buckets, s.d_part_a, s.d_part_b,
+                         s.d_heavy_ws, s.d_small + 26, stage1, stage2, ctx->small_lds_bytes);
+        if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], st));
+    } else {
+        HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)nbt * kXyzzBytes, st));  // zero = infinity
+        // hand over to the shared accumulation stream and back
+        hipStream_t hs = ctx->serialize_accum ? ctx->heavy_stream : st;
+        if (ctx->serialize_accum) {
+            HIP_TRY(ctx, hipEventRecord(s.sorted_ev, st));
+            HIP_TRY(ctx, hipStreamWaitEvent(hs, s.sorted_ev, 0));
+        }
+        if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 3], hs));
+        launch_bucket_accumulate(hs, ctx->d_table, s.d_sorted, s.d_offs, nbt, lanes, s.d_buckets, s.d_part_a, s.d_part_b,
+                                 ctx->accum_lds_bytes, s.d_pair_scratch, max_refs);
+        if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], hs));
+        if (ctx->serialize_accum) {
+            HIP_TRY(ctx, hipEventRecord(s.accum_ev, hs));
+            HIP_TRY(ctx, hipStreamWaitEvent(st, s.accum_ev, 0));
+        }
+        launch_bucket_finalize(st, s.d_offs, nbt, lanes, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_ws, s.d_small + 26,
+                               finalize_group_size(nbt), false);
+        // (gating the finalisation as well measured 3-5 % slower: it is short and wants to run at once)
+        if (ctx->gate_lds_bytes && !alone) hipLaunchKernelGGL(k_reduce_gate, dim3(1), dim3(64), ctx->gate_lds_bytes, st, (uint32_t*)nullptr);
+        launch_tree_sums_two_stage(st, stage1, 2, stage2, 4, (uint32_t*)s.d_heavy_ws + 64);
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 5], st));
     HIP_TRY(ctx, hipMemcpyAsync(s.h_final, s.d_final, ctx->final_records * batch * kXyzzBytes, hipMemcpyDeviceToHost,
@@ -529,6 +539,11 @@ int kzg_ctx_create(int device, kzg_ctx** out) {
     if (const char* v = std::getenv("KZG_SERIALIZE_ACCUM")) ctx->serialize_accum = std::atoi(v) != 0;
     if (const char* v = std::getenv("KZG_ACCUM_LDS_KB")) ctx->accum_lds_bytes = (uint32_t)std::atoi(v) * 1024u;
     if (const char* v = std::getenv("KZG_REDUCE_GATE_KB")) ctx->gate_lds_bytes = (uint32_t)std::atoi(v) * 1024u;
+    if (const char* v = std::getenv("KZG_SMALL_MSM")) ctx->small_msm_off = std::atoi(v) == 0;
+    if (hipFuncSetAttribute(small_msm_kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_msm_lds_bytes()) == hipSuccess)
+        ctx->small_lds_bytes = small_msm_lds_bytes();
+    else
+        (void)hipGetLastError();  // stays at 48 KiB: two workgroups may then share a CU (slower, not wrong)
     if (ctx->gate_lds_bytes > 64u * 1024u) {
         // more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
         if (hipFuncSetAttribute((const void*)k_reduce_gate, hipFuncAttributeMaxDynamicSharedMemorySize,

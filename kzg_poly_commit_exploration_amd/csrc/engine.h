@@ -68,6 +68,7 @@ void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_ar
                         uint64_t stride, uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt,
                         uint32_t* d_ws, uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted);
 // bucket accumulation (dominant kernel): one lane per segment of L sorted references
+constexpr size_t kHeavyHeaderBytes = 1024;  // zeroed per job: long-bucket counters (line 0), phase counters of the one-launch paths (own lines)
 constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on accumulate_lanes()
 // lanes (= segments) for at most max_refs references; a multiple of the workgroup size
 // alone: no other job is in flight on the context (the light kernels of other slots need no room)
@@ -80,13 +81,27 @@ void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t
                               void* d_part_a, void* d_part_b, uint32_t lds_reserve_bytes, void* d_pair_scratch,
                               uint64_t max_refs);
 // adds the head / tail partials of buckets that span several segments (serial for short runs, three passes of
-// 64-wide trees for long ones); d_heavy_ws: heavy_workspace_bytes() of scratch whose first 32 bytes (the
+// 64-wide trees for long ones); d_heavy_ws: heavy_workspace_bytes() of scratch whose first kHeavyHeaderBytes (the
 // counters) the caller has zeroed -- ahead of time, so that nothing sits between the end of the accumulation
 // and this launch (a fill kernel there lets the next slot's accumulation take the chip first: +0.9 ms)
 size_t heavy_workspace_bytes();
+// group: quads per bucket (finalize_group_size(nb); 1 = one quad per bucket, the throughput form); write_empty: empty
+// buckets are written as infinity by the kernel (the caller then skips the memset of d_buckets).
 void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t lanes, const void* d_part_a,
                             const void* d_part_b, void* d_buckets, void* d_heavy_ws,
-                            uint32_t* d_refs_out /* receives the number of references, may be null */);
+                            uint32_t* d_refs_out /* receives the number of references, may be null */, uint32_t group = 1,
+                            bool write_empty = false);
+uint32_t finalize_group_size(uint32_t nb);
+// Small jobs (at most kTinyRefs references, one polynomial): accumulation, finalisation, long-bucket trees and both
+// reduction stages in ONE launch (msm_finalize.hip: k_small_msm).  The first kHeavyHeaderBytes of d_heavy_ws must be zero.
+// lds_bytes: small_msm_lds_bytes() once hipFuncAttributeMaxDynamicSharedMemorySize has been raised for
+// small_msm_kernel(), otherwise at most 64 KiB.
+struct TreeSumDesc;
+uint32_t small_msm_lds_bytes();
+const void* small_msm_kernel();
+void launch_small_msm(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs, uint32_t nb,
+                      uint32_t lanes, void* d_buckets, void* d_part_a, void* d_part_b, void* d_heavy_ws, uint32_t* d_refs_out,
+                      const TreeSumDesc* stage1 /* 2 */, const TreeSumDesc* stage2 /* 4 */, uint32_t lds_bytes);
 // out[g] = sum_{q<len} in[g*gstride + q*estride], XYZZ records: log-depth tree per group;
 // up to four independent jobs per launch
 // group g reads in[(g / inner) * ostride + (g % inner) * gstride + q * estride], q < len
@@ -99,6 +114,10 @@ struct TreeSumDesc {
     uint64_t ostride;  // record stride between outer blocks
 };
 void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count);
+// stage2 reads what stage1 wrote.  One launch when both stages fit the chip at once (d_sync: two zeroed words, e.g.
+// words 4 and 5 of d_heavy_ws), otherwise two launches.
+void launch_tree_sums_two_stage(hipStream_t s, const TreeSumDesc* stage1, uint32_t count1, const TreeSumDesc* stage2,
+                                uint32_t count2, uint32_t* d_sync);
 
 // ---- srs_kernels.hip --------------------------------------------------------------------
 // blst_p1 Jacobian (host layout, strided) already copied to d_jac (n x 144 B contiguous) -> affine

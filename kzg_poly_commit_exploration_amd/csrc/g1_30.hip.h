@@ -284,6 +284,15 @@ __device__ __forceinline__ Fq fq_quad_broadcast(const Fq& v) {  // lane SRC of e
     }
     return r;
 }
+// KZG_QUAD_MUL_CALLS: the four products of a cooperative addition as calls of ONE copy of the multiplier per kernel
+// (operands and result in registers).  The kernels that use it run each addition site a handful of times per launch:
+// what they wait for is the instruction fetch of code they have never executed, and an inlined addition is 40 KB of it.
+#ifdef KZG_QUAD_MUL_CALLS
+static __device__ __noinline__ Fq fq_mul_quad_call(Fq a, Fq b) { return fq_mul(a, b); }
+#define KZG_QUAD_MUL(a, b) fq_mul_quad_call(a, b)
+#else
+#define KZG_QUAD_MUL(a, b) fq_mul(a, b)
+#endif
 __device__ __forceinline__ void xyzz30_add_quad(XYZZ30& acc, const XYZZ30& b, uint32_t q /* lane & 3 */) {
     if (xyzz30_is_inf(b)) return;
     if (xyzz30_is_inf(acc)) {
@@ -291,7 +300,7 @@ __device__ __forceinline__ void xyzz30_add_quad(XYZZ30& acc, const XYZZ30& b, ui
         return;
     }
     // stage 1
-    Fq t = fq_mul(fq_quad_select(q, acc.X, b.X, acc.Y, b.Y), fq_quad_select(q, b.ZZ, acc.ZZ, b.ZZZ, acc.ZZZ));
+    Fq t = KZG_QUAD_MUL(fq_quad_select(q, acc.X, b.X, acc.Y, b.Y), fq_quad_select(q, b.ZZ, acc.ZZ, b.ZZZ, acc.ZZZ));
     const Fq U1 = fq_quad_broadcast<0>(t), U2 = fq_quad_broadcast<1>(t), S1 = fq_quad_broadcast<2>(t), S2 = fq_quad_broadcast<3>(t);
     const Fq P = fq_norm(fq_sub_raw(U2, U1)), R = fq_norm(fq_sub_raw(S2, S1));
     if (fq_is_zero(P)) {
@@ -300,16 +309,16 @@ __device__ __forceinline__ void xyzz30_add_quad(XYZZ30& acc, const XYZZ30& b, ui
         return;
     }
     // stage 2
-    t = fq_mul(fq_quad_select(q, P, R, acc.ZZ, acc.ZZZ), fq_quad_select(q, P, R, b.ZZ, b.ZZZ));
+    t = KZG_QUAD_MUL(fq_quad_select(q, P, R, acc.ZZ, acc.ZZZ), fq_quad_select(q, P, R, b.ZZ, b.ZZZ));
     const Fq PP = fq_quad_broadcast<0>(t), RR = fq_quad_broadcast<1>(t), ZA = fq_quad_broadcast<2>(t), ZB = fq_quad_broadcast<3>(t);
     // stage 3
-    t = fq_mul(fq_quad_select(q, P, U1, ZA, P), PP);
+    t = KZG_QUAD_MUL(fq_quad_select(q, P, U1, ZA, P), PP);
     const Fq PPP = fq_quad_broadcast<0>(t), Q = fq_quad_broadcast<1>(t);
     acc.ZZ = fq_quad_broadcast<2>(t);
     const Fq X3 = fq_norm_wide(fq_sub_raw(fq_sub_raw(RR, PPP), fq_add_raw(Q, Q)));
     // stage 4
     const Fq QX = fq_norm(fq_sub_raw(Q, X3));
-    t = fq_mul(fq_quad_select(q, ZB, S1, R, ZB), fq_quad_select(q, PPP, PPP, QX, PPP));
+    t = KZG_QUAD_MUL(fq_quad_select(q, ZB, S1, R, ZB), fq_quad_select(q, PPP, PPP, QX, PPP));
     acc.ZZZ = fq_quad_broadcast<0>(t);
     acc.Y = fq_norm(fq_sub_raw(fq_quad_broadcast<2>(t), fq_quad_broadcast<1>(t)));
     acc.X = X3;
@@ -318,6 +327,39 @@ __device__ __forceinline__ void xyzz30_add_quad(XYZZ30& acc, const XYZZ30& b, ui
 
 // XYZZ record in HBM (engine.h kXyzzBytes = 256): coordinate c (X, Y, ZZ, ZZZ) in words 16 c .. 16 c + 12
 #ifdef __HIPCC__
+// The same for a wave in which only some quads have two finite operands.  Measured on MI355X (tools/microbench quad,
+// "tree_levels_us"): when the four waves of a workgroup run the addition with at most two quads (8 lanes) active
+// each, it takes 17-19 us instead of 5.5-6; with 16 or more active lanes per wave, or with a single wave running, it
+// does not.  So the quads that have nothing to add run the SAME instructions on two fixed operands (not curve points:
+// any two records with U2 != U1 take the generic path) and keep their own value: every lane of the wave stays active.
+// A wave in which no quad has anything to add skips the arithmetic altogether.
+__device__ __forceinline__ void xyzz30_add_quad_dense(XYZZ30& acc, const XYZZ30& b, uint32_t q /* lane & 3 */) {
+    const bool binf = xyzz30_is_inf(b), ainf = xyzz30_is_inf(acc);
+    const bool real = !binf && !ainf;
+    if (__builtin_amdgcn_ballot_w64(real) == 0) {
+        if (ainf) acc = b;
+        return;
+    }
+    const Fq one = fq_one(), two = fq_add_raw(one, one);
+    XYZZ30 a2, b2;
+    Fq* fa[4] = {&a2.X, &a2.Y, &a2.ZZ, &a2.ZZZ};
+    Fq* fb[4] = {&b2.X, &b2.Y, &b2.ZZ, &b2.ZZZ};
+    const Fq* sa[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
+    const Fq* sb[4] = {&b.X, &b.Y, &b.ZZ, &b.ZZZ};
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int i = 0; i < kQ; i++) {
+            fa[c]->d[i] = real ? sa[c]->d[i] : one.d[i];
+            fb[c]->d[i] = real ? sb[c]->d[i] : (c < 2 ? two.d[i] : one.d[i]);
+        }
+    xyzz30_add_quad(a2, b2, q);
+    Fq* fo[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int i = 0; i < kQ; i++) fo[c]->d[i] = real ? fa[c]->d[i] : (ainf ? sb[c]->d[i] : fo[c]->d[i]);
+}
 __device__ __forceinline__ Fq load_fq16(const uint4* __restrict__ p) {
     const uint4 a = p[0], b = p[1], c = p[2];
     const uint32_t d = reinterpret_cast<const uint32_t*>(p)[12];

@@ -20,6 +20,7 @@
 #define KZG_G1_30_NO_SB 1
 #include "engine.h"
 #include "g1_30.hip.h"
+#include "msm_tree_plan.h"
 
 namespace kzg {
 
@@ -27,36 +28,45 @@ constexpr int kCoop = 4;  // physical lanes per logical lane
 #define KZG_TREE_ADD(a, b) xyzz30_add_quad(a, b, threadIdx.x & 3u)
 #define KZG_TREE_WAVES 1
 
-constexpr int kTreeBlock = 256;
 
-// out[g] = sum_{q < len} in[g * gstride + q * estride]   for g < groups  (strides in XYZZ records).
-// A workgroup of 256 lanes serves 256 / lanes_per_group groups; each lane first adds its share of the
-// group serially (only when len > 256), then the lanes of a group fold in a tree through LDS.
-// Up to four independent jobs share one launch (their dependent-addition chains run side by side).
-struct TreeJob {
-    const uint4* in;
-    uint4* out;
-    uint32_t groups, len, lanes_per_group, first_block, inner;
-    uint64_t gstride, estride, ostride;
-};
 struct TreeJobs {
-    TreeJob j[4];
+    TreeJob j[6];
     uint32_t count;
+    // Two dependent stages in ONE launch (small jobs: a launch boundary costs more than a tree level).  sync[0] hands
+    // out workgroup numbers in the order the workgroups START, sync[1] counts finished stage-1 workgroups; a workgroup
+    // whose number is >= stage1_blocks waits for sync[1] == stage1_blocks.  Whoever holds such a number knows every
+    // stage-1 workgroup has started and depends on nothing, so the wait always ends -- whatever order the hardware
+    // dispatches workgroups in.  Null: plain launch, workgroup number = blockIdx.x.
+    uint32_t stage1_blocks;
+    uint32_t* sync;
 };
 
 __global__ void __launch_bounds__(kTreeBlock, KZG_TREE_WAVES) k_tree_sum(TreeJobs jobs) {
     constexpr int kLogical = kTreeBlock / kCoop;  // logical lanes per workgroup
     __shared__ uint32_t lds[4 * kQ * kLogical];
+    __shared__ uint32_t s_ticket;
     const int t = threadIdx.x / kCoop;
     const bool lead = (threadIdx.x & 3u) == 0;
+    uint32_t bid = blockIdx.x;
+    if (jobs.sync) {
+        if (threadIdx.x == 0) {
+            s_ticket = atomicAdd(&jobs.sync[0], 1u);
+            if (s_ticket >= jobs.stage1_blocks)
+                while (__hip_atomic_load(&jobs.sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < jobs.stage1_blocks)
+                    __builtin_amdgcn_s_sleep(4);
+        }
+        __syncthreads();
+        bid = s_ticket;
+        if (bid >= jobs.stage1_blocks) __threadfence();  // acquire: stage-1 results are read below
+    }
     uint32_t ji = 0;
 #pragma unroll
-    for (uint32_t q = 1; q < 4; q++)
-        if (q < jobs.count && blockIdx.x >= jobs.j[q].first_block) ji = q;
+    for (uint32_t q = 1; q < 6; q++)
+        if (q < jobs.count && bid >= jobs.j[q].first_block) ji = q;
     const TreeJob J = jobs.j[ji];
     const uint32_t lanes_per_group = J.lanes_per_group;
     const uint32_t gpb = kLogical / lanes_per_group;
-    const uint32_t g = (blockIdx.x - J.first_block) * gpb + t / lanes_per_group;
+    const uint32_t g = (bid - J.first_block) * gpb + t / lanes_per_group;
     const uint32_t l = t & (lanes_per_group - 1);
     XYZZ30 acc = xyzz30_inf();
     if (g < J.groups) {
@@ -87,41 +97,43 @@ __global__ void __launch_bounds__(kTreeBlock, KZG_TREE_WAVES) k_tree_sum(TreeJob
         }
     }
     if (lead && l == 0 && g < J.groups) store_xyzz30(J.out + (size_t)g * kXyzzU4, acc);
+    if (jobs.sync && bid < jobs.stage1_blocks) {
+        __threadfence();  // release: this workgroup's results before its count
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(&jobs.sync[1], 1u);
+    }
+}
+
+static uint32_t plan_jobs(TreeJobs& jobs, uint32_t first, const TreeSumDesc* descs, uint32_t count, uint32_t first_block) {
+    return plan_tree_jobs(jobs.j + first, descs, count, first_block, KZG_TREE_WAVES);
 }
 
 void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count) {
+    if (count > 6) count = 6;
     TreeJobs jobs;
     jobs.count = count;
-    // One (logical) lane per element gives the shortest chain (log2(len) dependent additions) but only ~1/log2(len)
-    // of the lane-steps do work.  A CU holds one workgroup (one wave per SIMD) = 64 logical lanes: beyond 256
-    // workgroups a second round would start, which costs a whole tree's latency -- lanes then pre-add several
-    // elements serially instead (one more dependent addition per doubling).
-    constexpr uint32_t kLogical = kTreeBlock / kCoop;
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < count && i < 4; i++) total += (uint64_t)descs[i].groups * descs[i].len;
-    const uint64_t resident_lanes = (uint64_t)KZG_TREE_WAVES * 256 * kLogical;
-    uint32_t per_lane = 1;
-    while ((total + per_lane - 1) / per_lane > resident_lanes && per_lane < 64) per_lane <<= 1;
-    uint32_t blocks = 0;
-    for (uint32_t i = 0; i < count && i < 4; i++) {
-        uint32_t lpg = 1;
-        while (lpg < descs[i].len && lpg < kLogical) lpg <<= 1;
-        lpg = lpg / per_lane ? lpg / per_lane : 1;
-        uint32_t gpb = kLogical / lpg;
-        jobs.j[i].in = reinterpret_cast<const uint4*>(descs[i].in);
-        jobs.j[i].out = reinterpret_cast<uint4*>(descs[i].out);
-        jobs.j[i].groups = descs[i].groups;
-        jobs.j[i].len = descs[i].len;
-        jobs.j[i].lanes_per_group = lpg;
-        jobs.j[i].first_block = blocks;
-        jobs.j[i].gstride = descs[i].gstride;
-        jobs.j[i].estride = descs[i].estride;
-        jobs.j[i].inner = descs[i].inner ? descs[i].inner : descs[i].groups;
-        jobs.j[i].ostride = descs[i].ostride;
-        blocks += (descs[i].groups + gpb - 1) / gpb;
-    }
+    jobs.stage1_blocks = 0;
+    jobs.sync = nullptr;
+    const uint32_t blocks = plan_jobs(jobs, 0, descs, count, 0);
     if (!blocks) return;
     hipLaunchKernelGGL(k_tree_sum, dim3(blocks), dim3(kTreeBlock), 0, s, jobs);
+}
+
+void launch_tree_sums_two_stage(hipStream_t s, const TreeSumDesc* stage1, uint32_t count1, const TreeSumDesc* stage2,
+                                uint32_t count2, uint32_t* d_sync) {
+    TreeJobs jobs;
+    jobs.count = count1 + count2;
+    const uint32_t b1 = count1 + count2 <= 6 ? plan_jobs(jobs, 0, stage1, count1, 0) : 0;
+    const uint32_t b2 = b1 ? plan_jobs(jobs, count1, stage2, count2, b1) : 0;
+    // one launch only while every workgroup is resident at once anyway (two per CU); else two launches
+    if (!d_sync || !b1 || !b2 || b1 + b2 > 512) {
+        launch_tree_sums(s, stage1, count1);
+        launch_tree_sums(s, stage2, count2);
+        return;
+    }
+    jobs.stage1_blocks = b1;
+    jobs.sync = d_sync;
+    hipLaunchKernelGGL(k_tree_sum, dim3(b1 + b2), dim3(kTreeBlock), 0, s, jobs);
 }
 
 }  // namespace kzg

@@ -41,6 +41,11 @@ MsmConfig choose_msm_config(size_t n, size_t table_budget_bytes) {
     double best = 1e300;
     for (uint32_t c = 8; c <= (naf ? 21u : 20u); c++) {
         if (fc >= 8 && fc <= (naf ? 21u : 20u) && c != fc) continue;
+        // Small jobs are latency-bound: a top window that holds only one or two bits of the (folded, < 2^254) scalars
+        // sends a half or a quarter of ALL points into one or two buckets, whose log-depth trees (50-80 us, measured
+        // at degree 1000 and 2500) then sit on the critical path.  Only widths whose top window keeps at least four
+        // bits are considered there: 8, 10, 13.
+        if (!naf && !fc && n <= 4096 && 254u - c * ((255 + c - 1) / c - 1) < 4u) continue;
         double cost = naf ? (double)n * (255.0 / (c + 1) + 0.5) + 8.0 * (double)(1u << (c - 2))
                           : (double)n * ((255 + c - 1) / c) + 8.0 * (double)(1u << (c - 1));
         if (cost < best) {

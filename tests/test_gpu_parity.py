@@ -744,6 +744,63 @@ print(json.dumps(out))
     assert res["1"] == res["0"]
 
 
+def test_small_jobs_one_launch_and_general_path_agree(oracle, golden):
+    """Jobs of up to 65536 references run accumulation, finalisation, long-bucket trees and both reduction stages as
+    phases of ONE launch (msm_finalize.hip: k_small_msm); KZG_SMALL_MSM=0 sends them through the general kernels
+    instead (group finalisation, two-stage tree launch).  Both must give the oracle's commitment: ragged sizes around
+    the workgroup and threshold boundaries, uniform and skewed coefficients (one bucket takes every point: the
+    long-bucket phase inside the launch), a degenerate secret (every SRS point equal: doublings in every tree)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import json, os, sys
+sys.path.insert(0, %r)
+import kzg_poly_commit_exploration_amd as K
+golden = json.load(open(os.path.join(%r, "tests", "golden", "golden.json")))
+secret = bytes.fromhex(golden["secret_be"])
+r = K.R_MODULUS
+out = {}
+for n in (1, 2, 3, 17, 64, 101, 257, 1001, 2501, 2521, 2731, 4096, 5000):
+    eng = K.SetupArtifactsGenerator(secret).take(n)
+    vals, p5 = [], 1
+    for _ in range(n):
+        vals.append((p5 + 10) %% r)
+        p5 = p5 * 5 %% r
+    out["bench_%%d" %% n] = eng.commit_limbs(K.scalars_to_limbs(vals)).compress().hex()
+    out["ones_%%d" %% n] = eng.commit_limbs(K.scalars_to_limbs([1] * n)).compress().hex()
+    out["neg_%%d" %% n] = eng.commit_limbs(K.scalars_to_limbs([r - 3] * n)).compress().hex()
+    out["sparse_%%d" %% n] = eng.commit_limbs(K.scalars_to_limbs([(i %% 7 == 0) * (i + 1) for i in range(n)])).compress().hex()
+    eng.close()
+e2 = K.SetupArtifactsGenerator((1).to_bytes(32, "big")).take(1500)
+out["secret_one"] = e2.commit_limbs(K.scalars_to_limbs([(i * i + 3) %% r for i in range(1500)])).compress().hex()
+e2.close()
+print(json.dumps(out))
+""" % (root, root)
+    res = {}
+    for mode in ("1", "0"):
+        env = dict(os.environ, KZG_SMALL_MSM=mode)
+        p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[mode] = __import__("json").loads(p.stdout.strip().splitlines()[-1])
+    assert res["1"] == res["0"]
+    secret = bytes.fromhex(golden["secret_be"])
+    r = K.R_MODULUS
+    for n in (1, 101, 2501, 2731, 5000):
+        vals, p5 = [], 1
+        for _ in range(n):
+            vals.append((p5 + 10) % r)
+            p5 = p5 * 5 % r
+        for name, coeffs in (("bench", vals), ("ones", [1] * n), ("neg", [r - 3] * n),
+                             ("sparse", [(i % 7 == 0) * (i + 1) for i in range(n)])):
+            want = oracle.p1_compress(oracle.commit_shortcut(K.scalars_to_limbs(coeffs), secret))
+            assert res["1"]["%s_%d" % (name, n)] == want.hex(), (name, n)
+    want = oracle.p1_compress(oracle.commit_shortcut(K.scalars_to_limbs([(i * i + 3) % r for i in range(1500)]),
+                                                     (1).to_bytes(32, "big")))
+    assert res["1"]["secret_one"] == want.hex()
+
+
 # ---------------------------------------------------------------- SRS wire / on-disk forms (SURVEY.md section 8f-4)
 
 def test_srs_binary_cache_affine_and_compressed_forms(engines, oracle, golden, tmp_path):

@@ -412,6 +412,126 @@ __global__ void __launch_bounds__(64) k_addquad_dbg(u32* io, int* tap) {
     add_quad_dbg(a, b, q, tap);
     tap[512 + threadIdx.x] = a.Y.d[0];
 }
+
+// ---- one workgroup of 64 quads folding 64 points through LDS (the shape of k_tree_sum / tree64), with the constant
+// 100 MHz clock read by thread 0 after every level: where does a tree level's time go?
+__global__ void __launch_bounds__(256, 1) k_tree_probe(u32* io, unsigned long long* stamps, int mode) {
+    // mode 0: one tree over the 64 quads; mode 2 / 3 / 4: independent trees over groups of 16 / 8 / 4 quads (every wave
+    // keeps 1, 2 or 4 quads busy down to the last level)
+    __shared__ uint32_t lds[4 * kQ * 64];
+    const int t = threadIdx.x / 4;
+    const uint32_t q = threadIdx.x & 3u;
+    const bool lead = q == 0;
+    const int gsz = mode == 0 ? 64 : (mode == 2 || mode == 5) ? 16 : mode == 3 ? 8 : 4;
+    const int l = t & (gsz - 1);
+    Affine30 p;
+    p.x = fq_mul(fq_from_u32x12(io), fq_one());
+    p.y = fq_mul(fq_from_u32x12(io + 12), fq_one());
+    XYZZ30 acc = xyzz30_inf();
+    xyzz30_madd(acc, p, false);
+    xyzz30_madd(acc, p, false);
+    for (int k = 0; k < t; k++) xyzz30_madd(acc, p, false);  // (2 + t) P: all 64 differ, and so do all partial sums
+    __syncthreads();
+    stamps += blockIdx.x * 8;
+    if (threadIdx.x == 0) stamps[0] = wall_clock64();
+    int lvl = 1;
+    for (int off = gsz >> 1; off >= 1; off >>= 1, lvl++) {
+        __syncthreads();
+        if (lead && l >= off && l < 2 * off) {
+            const Fq* f[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int i = 0; i < kQ; i++) lds[(c * kQ + i) * 64 + (t - off)] = (uint32_t)f[c]->d[i];
+        }
+        __syncthreads();
+        if (mode == 5) {  // every quad enters; those without a partner bring an operand at infinity
+            XYZZ30 o = xyzz30_inf();
+            if (l < off) {
+                Fq* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int i = 0; i < kQ; i++) f[c]->d[i] = (int32_t)lds[(c * kQ + i) * 64 + t];
+            }
+            xyzz30_add_quad_dense(acc, o, q);
+        } else if (l < off) {
+            XYZZ30 o;
+            Fq* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int i = 0; i < kQ; i++) f[c]->d[i] = (int32_t)lds[(c * kQ + i) * 64 + t];
+            xyzz30_add_quad(acc, o, q);
+        }
+        if (threadIdx.x == 0) stamps[lvl] = wall_clock64();
+    }
+    for (; lvl < 7; lvl++)
+        if (threadIdx.x == 0) stamps[lvl] = stamps[lvl - 1];
+    if (threadIdx.x == 0) {
+        fq_to_u32x12(acc.X, io + 24);
+        fq_to_u32x12(acc.Y, io + 36);
+    }
+}
+// Four waves of one workgroup running the cooperative addition out of phase with each other (wave w starts w * skew
+// later): does a wave's addition take longer when its neighbours on the CU are at other places of the same code?
+__global__ void __launch_bounds__(256, 1) k_phase_probe(u32* io, unsigned long long* stamps, int skew_sleeps, int active_waves) {
+    const uint32_t q = threadIdx.x & 3u;
+    const int w = threadIdx.x >> 6;
+    Affine30 p;
+    p.x = fq_mul(fq_from_u32x12(io), fq_one());
+    p.y = fq_mul(fq_from_u32x12(io + 12), fq_one());
+    XYZZ30 a = xyzz30_inf(), b = xyzz30_inf();
+    xyzz30_madd(a, p, false);
+    xyzz30_madd(a, p, false);
+    xyzz30_dbl_inplace(a);
+    xyzz30_madd(b, p, false);
+    xyzz30_madd(b, p, false);
+    xyzz30_madd(b, p, false);
+    __syncthreads();
+    if (w < active_waves) {
+        for (int k = 0; k < w * skew_sleeps; k++) __builtin_amdgcn_s_sleep(16);
+        for (int it = 0; it < 4; it++) {
+            const unsigned long long t0 = wall_clock64();
+            xyzz30_add_quad(a, b, q);
+            const unsigned long long t1 = wall_clock64();
+            if ((threadIdx.x & 63) == 0) {
+                stamps[(blockIdx.x * 4 + w) * 8 + it * 2] = t0;
+                stamps[(blockIdx.x * 4 + w) * 8 + it * 2 + 1] = t1;
+            }
+        }
+    }
+    if (a.X.d[3] == 0x12345 && a.Y.d[2] == 77) io[80] = 1;
+}
+
+// One wave: `active` of its 16 quads run the cooperative addition; the others either skip it (mode 0) or enter it
+// with an operand at infinity and leave through its early exit (mode 1), as in the step loop of k_small_msm.
+__global__ void __launch_bounds__(256, 1) k_partial_probe(u32* io, unsigned long long* stamps, int active, int mode) {
+    const uint32_t q = threadIdx.x & 3u;
+    const int quad = (threadIdx.x & 63) >> 2;
+    Affine30 p;
+    p.x = fq_mul(fq_from_u32x12(io), fq_one());
+    p.y = fq_mul(fq_from_u32x12(io + 12), fq_one());
+    XYZZ30 a = xyzz30_inf(), b = xyzz30_inf();
+    xyzz30_madd(a, p, false);
+    xyzz30_madd(a, p, false);
+    xyzz30_dbl_inplace(a);
+    xyzz30_madd(b, p, false);
+    xyzz30_madd(b, p, false);
+    xyzz30_madd(b, p, false);
+    if (quad >= active && mode == 1) b = xyzz30_inf();
+    __syncthreads();
+    for (int it = 0; it < 4; it++) {
+        const unsigned long long t0 = wall_clock64();
+        if (quad < active || mode == 1) xyzz30_add_quad(a, b, q);
+        const unsigned long long t1 = wall_clock64();
+        if (threadIdx.x == 0) {
+            stamps[it * 2] = t0;
+            stamps[it * 2 + 1] = t1;
+        }
+    }
+    if (a.X.d[3] == 0x12345 && a.Y.d[2] == 77) io[80] = 1;
+}
 __global__ void __launch_bounds__(256) k_dpp_probe(int* out) {
     const int v = threadIdx.x * 10;
     out[threadIdx.x] = __builtin_amdgcn_mov_dpp(v, 2 * 0x55, 0xf, 0xf, true);
@@ -813,6 +933,57 @@ static int run_quad() {
         CHECK(hipMemcpy(hc, cmp, 96 * 4, hipMemcpyDeviceToHost));
         printf("{\"probe\": \"add_quad_vs_add\", \"iters\": %d, \"lanes_point_differs\": %d, \"lanes_digits_differ\": %d}\n", iters, hc[0], hc[1]);
         for (int k = 0; k < 16; k++) printf("  lane %d mask %x quadY0 %d quadY12 %d refY0 %d refY12 %d\n", k, hc[8 + k], hc[32 + k], hc[48 + k], hc[64 + k], hc[80 + k]);
+    }
+    {
+        unsigned long long* st;
+        static unsigned long long hs[8];
+        CHECK(hipMalloc(&st, sizeof hs));
+        for (int mode = 0; mode < 2; mode++)
+            for (int active : {16, 8, 4, 2, 1}) {
+                CHECK(hipMemcpy(dio, hin, sizeof hin, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_partial_probe, dim3(1), dim3(64), 0, 0, dio, st, active, mode);
+                CHECK(hipMemcpy(hs, st, sizeof hs, hipMemcpyDeviceToHost));
+                printf("{\"probe\": \"partially_active_wave\", \"mode\": %d, \"active_quads\": %d, \"add_us\": [%.1f, %.1f, %.1f, %.1f]}\n", mode, active,
+                       (hs[1] - hs[0]) / 100.0, (hs[3] - hs[2]) / 100.0, (hs[5] - hs[4]) / 100.0, (hs[7] - hs[6]) / 100.0);
+            }
+    }
+    {
+        unsigned long long* st;
+        static unsigned long long hs[8 * 4];
+        CHECK(hipMalloc(&st, sizeof hs));
+        for (int waves : {1, 2, 4})
+            for (int skew : {0, 1, 3, 6}) {
+                CHECK(hipMemcpy(dio, hin, sizeof hin, hipMemcpyHostToDevice));
+                CHECK(hipMemset(st, 0, sizeof hs));
+                hipLaunchKernelGGL(k_phase_probe, dim3(1), dim3(256), 0, 0, dio, st, skew, waves);
+                CHECK(hipMemcpy(hs, st, sizeof hs, hipMemcpyDeviceToHost));
+                printf("{\"probe\": \"out_of_phase_waves\", \"active_waves\": %d, \"skew_sleeps\": %d, \"add_us_per_wave\": [", waves, skew);
+                for (int w = 0; w < waves; w++) {
+                    printf("%s[", w ? ", " : "");
+                    for (int it = 0; it < 4; it++) printf("%s%.1f", it ? ", " : "", (hs[w * 8 + it * 2 + 1] - hs[w * 8 + it * 2]) / 100.0);
+                    printf("] @%.1f", (hs[w * 8] - hs[0]) / 100.0);
+                }
+                printf("]}\n");
+            }
+    }
+    {
+        unsigned long long* st;
+        static unsigned long long hs[8 * 256];
+        CHECK(hipMalloc(&st, sizeof hs));
+        for (int wgs : {1, 56})
+            for (int rep : {0, 2, 5, 3, 4}) {  // rep = mode
+                CHECK(hipMemcpy(dio, hin, sizeof hin, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_tree_probe, dim3(wgs), dim3(256), 0, 0, dio, st, rep);
+                CHECK(hipMemcpy(hs, st, sizeof hs, hipMemcpyDeviceToHost));
+                printf("{\"probe\": \"tree_levels_us\", \"workgroups\": %d, \"mode\": %d, \"min_med_max_per_level\": [", wgs, rep);
+                for (int l = 0; l < 6; l++) {
+                    std::vector<double> v;
+                    for (int w = 0; w < wgs; w++) v.push_back((hs[w * 8 + l + 1] - hs[w * 8 + l]) / 100.0);
+                    std::sort(v.begin(), v.end());
+                    printf("%s[%.1f, %.1f, %.1f]", l ? ", " : "", v[0], v[v.size() / 2], v.back());
+                }
+                printf("]}\n");
+            }
     }
     for (int it = 0; it < 2; it++) {
         CHECK(hipMemcpy(dio, hin, sizeof hin, hipMemcpyHostToDevice));
