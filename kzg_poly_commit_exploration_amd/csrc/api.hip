@@ -338,8 +338,8 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
     const uint32_t nbt = cfg.nb * batch;  // polynomial-major bucket ids
     hipStream_t st = s.stream;
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base], st));
-    launch_bucket_sort(st, d_scalars, is_mont, (uint32_t)n, batch, stride, (uint32_t)ctx->n, cfg, s.d_cnt,
-                       s.d_block_sums, s.d_pairs, s.d_offs, s.d_sorted);
+    const bool header_zeroed = launch_bucket_sort(st, d_scalars, is_mont, (uint32_t)n, batch, stride, (uint32_t)ctx->n, cfg, s.d_cnt,
+                       s.d_block_sums, s.d_pairs, s.d_offs, s.d_sorted, (uint32_t*)s.d_heavy_ws);
     if (s.timing) {
         HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 1], st));
         HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 2], st));
@@ -364,7 +364,7 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         {row, fin + (size_t)P.off_c2row * B * kXyzzBytes, B * rl, rh, 1, rl, rl, R},
         {col, fin + (size_t)P.off_r2col * B * kXyzzBytes, B * ch, cl, cl, 1, ch, C},
         {col, fin + (size_t)P.off_c2col * B * kXyzzBytes, B * cl, ch, 1, cl, cl, C}};
-    HIP_TRY(ctx, hipMemsetAsync(s.d_heavy_ws, 0, kHeavyHeaderBytes, st));  // long-bucket counters, phase counters
+    if (!header_zeroed) HIP_TRY(ctx, hipMemsetAsync(s.d_heavy_ws, 0, kHeavyHeaderBytes, st));  // long-bucket counters, phase counters
     if (max_refs <= kTinyRefs && !ctx->small_msm_off) {
         // Small jobs are chains of dependent additions on a nearly empty chip: everything from here to the copy back
         // in ONE launch on the slot's own stream (msm_finalize.hip: k_small_msm), no bucket memset, no stream hand-over.
@@ -840,7 +840,12 @@ static int submit_commit_locked(kzg_ctx* ctx, int slot, const uint32_t* d_scalar
     s.tail_checked = tail_already_checked;
     std::memset(&s.times, 0, sizeof s.times);
     size_t n_msm = n < ctx->n ? n : ctx->n;
-    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    // The flag words only matter when there is a tail beyond the SRS to check, a trivial job to report or kernel
+    // statistics to return: a plain commitment skips their memset and their copy back (two stream operations of the
+    // ~8 a small commitment consists of) and reads zeros.
+    const bool need_small = (n > ctx->n && !tail_already_checked) || n_msm == 0 || s.timing;
+    if (need_small) HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    else std::memset(s.h_small, 0, 64 * 4);
     if (n > ctx->n && !tail_already_checked) {
         // reference: the Polynomial was truncated at construction (src/polynomial.rs:55-75), so only a
         // non-zero coefficient beyond the SRS makes the degree too high (src/polynomial.rs:201-205)
@@ -854,7 +859,7 @@ static int submit_commit_locked(kzg_ctx* ctx, int slot, const uint32_t* d_scalar
     }
     int rc = enqueue_msm(ctx, s, d_scalars, is_mont, n_msm, 0);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
+    if (need_small) HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
     s.kind = SLOT_COMMIT;
     return KZG_OK;

@@ -56,6 +56,7 @@ __host__ __device__ inline uint32_t accumulate_seg_len(uint32_t M, uint32_t lane
 }
 
 // ---- msm_kernels.hip --------------------------------------------------------------------
+constexpr size_t kHeavyHeaderBytes = 1024;  // zeroed per job: long-bucket counters (line 0), phase counters of the one-launch paths (own lines)
 // scalar recoding + two-level LDS counting sort of `batch` polynomials of n terms at once (polynomial p
 // at d_scalars + p * stride scalars; its buckets are [p * nb, (p+1) * nb)): fills
 // d_offs[0 .. batch*nb] (last = number of references) and d_sorted (bucket-major table references,
@@ -64,11 +65,12 @@ __host__ __device__ inline uint32_t accumulate_seg_len(uint32_t M, uint32_t lane
 uint32_t sort_count_entries(uint32_t max_batch, MsmConfig cfg);
 uint32_t sort_max_batch(MsmConfig cfg);
 uint32_t sort_workspace_words();
-void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n, uint32_t batch,
+// d_header: kHeavyHeaderBytes that the job wants zeroed before its next kernel; returns true when the sort did that
+// itself (the one-kernel sort of small jobs), false when the caller has to memset them.
+bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n, uint32_t batch,
                         uint64_t stride, uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt,
-                        uint32_t* d_ws, uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted);
+                        uint32_t* d_ws, uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted, uint32_t* d_header);
 // bucket accumulation (dominant kernel): one lane per segment of L sorted references
-constexpr size_t kHeavyHeaderBytes = 1024;  // zeroed per job: long-bucket counters (line 0), phase counters of the one-launch paths (own lines)
 constexpr uint32_t kMaxAccumLanes = 262144 + 64;  // bound on accumulate_lanes()
 // lanes (= segments) for at most max_refs references; a multiple of the workgroup size
 // alone: no other job is in flight on the context (the light kernels of other slots need no room)

@@ -576,8 +576,10 @@ constexpr int kSmallSortBlock = 1024;
 __global__ void __launch_bounds__(kSmallSortBlock) k_sort_small(const uint32_t* __restrict__ d_scalars, int is_mont, uint32_t n,
                                                                 uint32_t table_stride, MsmConfig cfg,
                                                                 uint32_t* __restrict__ d_offs,
-                                                                uint32_t* __restrict__ d_sorted) {
+                                                                uint32_t* __restrict__ d_sorted,
+                                                                uint32_t* __restrict__ d_header) {
     __shared__ u32 s_hist[kSmallSortBuckets];
+    if (blockIdx.x == 0 && threadIdx.x < kHeavyHeaderBytes / 4) d_header[threadIdx.x] = 0;  // the job's counters
     __shared__ u32 s_part[kSmallSortBlock];
     const uint32_t t = threadIdx.x;
     const uint32_t nb = cfg.nb;
@@ -616,25 +618,32 @@ __global__ void __launch_bounds__(kSmallSortBlock) k_sort_small(const uint32_t* 
     }
     if (t == kSmallSortBlock - 1) d_offs[nb] = s_part[t];
     __syncthreads();
+    // Every workgroup of the launch has computed the same offsets; each scatters the references of its own range of
+    // buckets (the scattered 4-byte stores of one CU are what this kernel waits for: 51 us at degree 2500 alone).
+    const uint32_t b_lo = (uint32_t)((uint64_t)nb * blockIdx.x / gridDim.x), b_hi = (uint32_t)((uint64_t)nb * (blockIdx.x + 1) / gridDim.x);
     for (uint32_t i = t; i < n; i += kSmallSortBlock) {
         u32 k[8];
         const bool flip = load_scalar(d_scalars, i, is_mont, k);
         for_each_digit(k, cfg, [&](uint32_t j, u32 bkt, bool neg) {
-            u32 pos = atomicAdd(&s_hist[bkt], 1u);
-            d_sorted[pos] = (j * table_stride + i) | ((neg != flip) ? 0x80000000u : 0u);
+            if (bkt >= b_lo && bkt < b_hi) {
+                u32 pos = atomicAdd(&s_hist[bkt], 1u);
+                d_sorted[pos] = (j * table_stride + i) | ((neg != flip) ? 0x80000000u : 0u);
+            }
         });
     }
 }
 
-void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, uint32_t n, uint32_t batch,
+bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, uint32_t n, uint32_t batch,
                         uint64_t stride, uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt, uint32_t* d_ws,
-                        uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted) {
-    if (n == 0 || batch == 0) return;
+                        uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted, uint32_t* d_header) {
+    if (n == 0 || batch == 0) return false;
     static const bool small_path = [] { const char* v = std::getenv("KZG_SMALL_SORT"); return !(v && v[0] == '0'); }();
     if (small_path && batch == 1 && n <= kSmallSortScalars && cfg.nb <= kSmallSortBuckets) {
-        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(kSmallSortBlock), 0, s, d_scalars, is_mont, n, table_stride, cfg, d_offs,
-                           d_sorted);
-        return;
+        uint32_t groups = n / 256;  // workgroups sharing the scatter: 1 ... 8
+        groups = groups < 1 ? 1 : (groups > 8 ? 8 : groups);
+        hipLaunchKernelGGL(k_sort_small, dim3(groups), dim3(kSmallSortBlock), 0, s, d_scalars, is_mont, n, table_stride, cfg, d_offs,
+                           d_sorted, d_header);
+        return true;
     }
     const uint32_t nb_total = cfg.nb * batch;
     SortGeom g = sort_geometry((uint64_t)n * batch, nb_total, cfg);
@@ -661,6 +670,7 @@ void launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, u
                        g.coarse_bins, nb_total, d_total, d_prefix, d_table, d_offs);
     hipLaunchKernelGGL(k_fine_scatter, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
                        g.coarse_bins, d_total, ch, d_prefix, d_table, d_sorted);
+    return false;
 }
 
 }  // namespace kzg
