@@ -371,48 +371,6 @@ __global__ void __launch_bounds__(256) k_addquad(u32* io, int iters, int* cmp) {
     }
 }
 
-__device__ __forceinline__ void add_quad_dbg(XYZZ30& acc, const XYZZ30& b, uint32_t q, int* tap) {
-    Fq t = fq_mul(fq_quad_select(q, acc.X, b.X, acc.Y, b.Y), fq_quad_select(q, b.ZZ, acc.ZZ, b.ZZZ, acc.ZZZ));
-    const Fq U1 = fq_quad_broadcast<0>(t), U2 = fq_quad_broadcast<1>(t), S1 = fq_quad_broadcast<2>(t), S2 = fq_quad_broadcast<3>(t);
-    const Fq P = fq_norm(fq_sub_raw(U2, U1)), R = fq_norm(fq_sub_raw(S2, S1));
-    t = fq_mul(fq_quad_select(q, P, R, acc.ZZ, acc.ZZZ), fq_quad_select(q, P, R, b.ZZ, b.ZZZ));
-    const Fq PP = fq_quad_broadcast<0>(t), RR = fq_quad_broadcast<1>(t), ZA = fq_quad_broadcast<2>(t), ZB = fq_quad_broadcast<3>(t);
-    t = fq_mul(fq_quad_select(q, P, U1, ZA, P), PP);
-    const Fq PPP = fq_quad_broadcast<0>(t), Q = fq_quad_broadcast<1>(t);
-    acc.ZZ = fq_quad_broadcast<2>(t);
-    const Fq X3 = fq_norm_wide(fq_sub_raw(fq_sub_raw(RR, PPP), fq_add_raw(Q, Q)));
-    const Fq QX = fq_norm(fq_sub_raw(Q, X3));
-    const Fq sa = fq_quad_select(q, ZB, S1, R, ZB), sb = fq_quad_select(q, PPP, PPP, QX, PPP);
-    t = fq_mul(sa, sb);
-    const Fq b0 = fq_quad_broadcast<0>(t), b1 = fq_quad_broadcast<1>(t), b2 = fq_quad_broadcast<2>(t);
-    tap[threadIdx.x * 8 + 0] = t.d[0];
-    tap[threadIdx.x * 8 + 1] = b0.d[0];
-    tap[threadIdx.x * 8 + 2] = b1.d[0];
-    tap[threadIdx.x * 8 + 3] = b2.d[0];
-    tap[threadIdx.x * 8 + 4] = sa.d[0];
-    tap[threadIdx.x * 8 + 5] = sb.d[0];
-    tap[threadIdx.x * 8 + 6] = S1.d[0];
-    tap[threadIdx.x * 8 + 7] = R.d[0];
-    acc.ZZZ = b0;
-    acc.Y = fq_norm(fq_sub_raw(b2, b1));
-    acc.X = X3;
-}
-__global__ void __launch_bounds__(64) k_addquad_dbg(u32* io, int* tap) {
-    const uint32_t q = threadIdx.x & 3u;
-    Affine30 p;
-    p.x = fq_mul(fq_from_u32x12(io), fq_one());
-    p.y = fq_mul(fq_from_u32x12(io + 12), fq_one());
-    XYZZ30 a = xyzz30_inf(), b = xyzz30_inf();
-    xyzz30_madd(a, p, false);
-    xyzz30_madd(a, p, false);
-    xyzz30_dbl_inplace(a);  // 4P
-    xyzz30_madd(b, p, false);
-    xyzz30_madd(b, p, false);
-    xyzz30_madd(b, p, false);  // 3P
-    add_quad_dbg(a, b, q, tap);
-    tap[512 + threadIdx.x] = a.Y.d[0];
-}
-
 // ---- one workgroup of 64 quads folding 64 points through LDS (the shape of k_tree_sum / tree64), with the constant
 // 100 MHz clock read by thread 0 after every level: where does a tree level's time go?
 __global__ void __launch_bounds__(256, 1) k_tree_probe(u32* io, unsigned long long* stamps, int mode) {
@@ -915,24 +873,14 @@ static int run_quad() {
     hipLaunchKernelGGL(k_dpp_probe, dim3(1), dim3(64), 0, 0, cmp);
     CHECK(hipMemcpy(hc, cmp, 256, hipMemcpyDeviceToHost));
     printf("{\"probe\": \"dpp_quad_broadcast_lane2\", \"first8\": [%d, %d, %d, %d, %d, %d, %d, %d]}\n", hc[0], hc[1], hc[2], hc[3], hc[4], hc[5], hc[6], hc[7]);
-    {
-        int* tap;
-        int ht[1024];
-        CHECK(hipMalloc(&tap, sizeof ht));
-        CHECK(hipMemset(tap, 0, sizeof ht));
-        CHECK(hipMemcpy(dio, hin, sizeof hin, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_addquad_dbg, dim3(1), dim3(64), 0, 0, dio, tap);
-        CHECK(hipMemcpy(ht, tap, sizeof ht, hipMemcpyDeviceToHost));
-        for (int l = 0; l < 8; l++)
-            printf("  dbg lane %d t %d b0 %d b1 %d b2 %d sa %d sb %d S1 %d R %d Y %d\n", l, ht[l * 8], ht[l * 8 + 1], ht[l * 8 + 2], ht[l * 8 + 3], ht[l * 8 + 4], ht[l * 8 + 5], ht[l * 8 + 6], ht[l * 8 + 7], ht[512 + l]);
-    }
     for (int iters = 1; iters <= 4; iters++) {
         CHECK(hipMemcpy(dio, hin, sizeof hin, hipMemcpyHostToDevice));
         CHECK(hipMemset(cmp, 0, 1024));
         hipLaunchKernelGGL(k_addquad, dim3(2), dim3(256), 0, 0, dio, iters, cmp);
         CHECK(hipMemcpy(hc, cmp, 96 * 4, hipMemcpyDeviceToHost));
         printf("{\"probe\": \"add_quad_vs_add\", \"iters\": %d, \"lanes_point_differs\": %d, \"lanes_digits_differ\": %d}\n", iters, hc[0], hc[1]);
-        for (int k = 0; k < 16; k++) printf("  lane %d mask %x quadY0 %d quadY12 %d refY0 %d refY12 %d\n", k, hc[8 + k], hc[32 + k], hc[48 + k], hc[64 + k], hc[80 + k]);
+        if (hc[0])  // per-lane detail of the first quads: which coordinates (bit 0 X, 1 Y, 2 ZZ, 3 ZZZ) agree digit for digit
+            for (int k = 0; k < 16; k++) printf("  lane %d mask %x quadY0 %d quadY12 %d refY0 %d refY12 %d\n", k, hc[8 + k], hc[32 + k], hc[48 + k], hc[64 + k], hc[80 + k]);
     }
     {
         unsigned long long* st;
