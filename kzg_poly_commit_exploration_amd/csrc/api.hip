@@ -889,18 +889,22 @@ static int submit_open_locked(kzg_ctx* ctx, int slot, const uint32_t* d_coeffs, 
     s.tail_checked = false;
     std::memcpy(s.open_y, y, 32);
     std::memset(&s.times, 0, sizeof s.times);
-    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
     if (n == 0) {
+        HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
         s.kind = SLOT_TRIVIAL;
         return KZG_OK;
     }
     uint32_t zw[8];
     std::memcpy(zw, z, 32);
-    PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[6], s.stream));
-    launch_quotient(s.stream, d_coeffs, (uint32_t)n, zw, n > 1 ? s.d_q : nullptr, sc);
+    // small polynomials: one launch for the scan, the flag words and c0; otherwise memset + three launches + a copy
+    if (!launch_quotient_single(s.stream, d_coeffs, (uint32_t)n, zw, n > 1 ? s.d_q : nullptr, s.d_small)) {
+        HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+        PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
+        launch_quotient(s.stream, d_coeffs, (uint32_t)n, zw, n > 1 ? s.d_q : nullptr, sc);
+        HIP_TRY(ctx, hipMemcpyAsync(s.d_small + 16, d_coeffs, 32, hipMemcpyDeviceToDevice, s.stream));  // c0
+    }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[7], s.stream));
-    HIP_TRY(ctx, hipMemcpyAsync(s.d_small + 16, d_coeffs, 32, hipMemcpyDeviceToDevice, s.stream));  // c0
     size_t nq = n - 1;
     if (nq > ctx->n) {
         // quotient longer than the SRS: too high iff some coefficient with index > srs_len is non-zero

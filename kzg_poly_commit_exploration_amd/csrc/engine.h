@@ -178,6 +178,10 @@ size_t poly_chunk_words(uint32_t n);
 size_t poly_block_words(uint32_t n);
 // suffix Horner scan S[i] = sum_{k>=i} c[k] z^(k-i):  q[i-1] = S[i] (i >= 1) when d_q != nullptr,
 // P(z) = S[0] to scratch.d_result; flags as above.  z in Montgomery form (8 words, host copy).
+// n <= 4096: one launch that also fills the slot's 64 flag words completely (P(z) at +8, c[0] at +16, flag at +0,
+// zeros elsewhere); returns false (nothing enqueued) for larger n.
+bool launch_quotient_single(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const uint32_t z_mont[8], uint32_t* d_q,
+                            uint32_t* d_small);
 void launch_quotient(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const uint32_t z_mont[8],
                      uint32_t* d_q, PolyScratch scratch);
 

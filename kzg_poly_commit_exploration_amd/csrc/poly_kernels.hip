@@ -175,6 +175,79 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_apply(const uint32_t* __res
     }
 }
 
+// Up to kPolySingleMax coefficients (the reference's bench degrees): the whole scan in ONE workgroup and one launch --
+// chunk Horner, Kogge-Stone over the 256 lanes, replay from the neighbour's value.  It also writes the 64 flag words
+// of the slot in full (P(z) at [8..15], c[0] at [16..23], [0] = any non-zero coefficient with index >= 1, zero
+// elsewhere), which saves the caller a memset and a device-to-device copy: five stream operations become one.
+constexpr uint32_t kPolySingleL = 16;
+constexpr uint32_t kPolySingleMax = kPolySingleL * kPolyBlock;  // 4096
+__global__ void __launch_bounds__(kPolyBlock) k_poly_single(const uint32_t* __restrict__ coeffs, uint32_t n, PolyPowers pw,
+                                                            uint32_t* __restrict__ d_q, uint32_t* __restrict__ d_small) {
+    __shared__ uint32_t lds[kPolyBlock * 8];
+    const Fr z = fr_from_arg(pw.z);
+    const uint32_t t = threadIdx.x;
+    const uint32_t base = t * kPolySingleL;
+    Fr h = Fr::zero();
+    bool nz = false;
+#pragma unroll 1
+    for (int k = (int)kPolySingleL - 1; k >= 0; k--) {
+        const uint32_t idx = base + k;
+        h = fe_mul(h, z);
+        if (idx < n) {
+            const Fr c = load_fr(coeffs + (size_t)idx * 8);
+            if (idx >= 1 && !c.is_zero()) nz = true;
+            h = fe_add(h, c);
+        }
+    }
+    const int any_nz = __syncthreads_or(nz ? 1 : 0);
+    h = block_suffix_scan<kPolyBlock>(h, pw.zl_sq, lds);  // S at the first coefficient of this lane's chunk
+#pragma unroll
+    for (int i = 0; i < 8; i++) lds[i * kPolyBlock + t] = h.l[i];
+    __syncthreads();
+    if (t < 64) d_small[t] = 0;
+    __syncthreads();
+    if (t == 0) {
+        d_small[0] = any_nz ? 1u : 0u;
+        store_fr(d_small + 8, h);  // S[0] = P(z)
+        store_fr(d_small + 16, load_fr(coeffs));
+    }
+    if (!d_q || n <= 1) return;
+    Fr carry = Fr::zero();  // S at the first coefficient of the next chunk
+    if (t + 1 < (uint32_t)kPolyBlock) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) carry.l[i] = lds[i * kPolyBlock + t + 1];
+    }
+    h = carry;
+#pragma unroll 1
+    for (int k = (int)kPolySingleL - 1; k >= 0; k--) {
+        const uint32_t idx = base + k;
+        h = fe_mul(h, z);
+        if (idx < n) {
+            h = fe_add(h, load_fr(coeffs + (size_t)idx * 8));
+            if (idx >= 1) store_fr(d_q + (size_t)(idx - 1) * 8, h);
+        }
+    }
+}
+
+bool launch_quotient_single(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const uint32_t z_mont[8], uint32_t* d_q,
+                            uint32_t* d_small) {
+    if (n == 0 || n > kPolySingleMax) return false;
+    namespace hf = kzg_host;
+    PolyPowers pw;
+    std::memset(&pw, 0, sizeof pw);
+    auto put = [](FrArg& dst, const hf::Fr& v) { std::memcpy(dst.l, v.l, 32); };
+    hf::Fr z;
+    std::memcpy(z.l, z_mont, 32);
+    put(pw.z, z);
+    hf::Fr m = hf::fr_pow(z, kPolySingleL);
+    for (int k = 0; k < 8; k++) {  // (z^L)^(2^k)
+        put(pw.zl_sq[k], m);
+        m = hf::fr_mul(m, m);
+    }
+    hipLaunchKernelGGL(k_poly_single, dim3(1), dim3(kPolyBlock), 0, s, d_coeffs, n, pw, d_q, d_small);
+    return true;
+}
+
 void launch_quotient(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const uint32_t z_mont[8], uint32_t* d_q,
                      PolyScratch sc) {
     if (n == 0) return;

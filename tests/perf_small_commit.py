@@ -44,12 +44,27 @@ def run(degree, reps=400):
         eng.commit_submit(0, d, n)
         eng.wait(0)
     lat = (time.perf_counter() - t0) / 100
+    # the reference's other benches at the same degrees: evaluation proof (benches/evaluation_proof.rs) and evaluation
+    # (benches/polynomial_evaluation.rs), one at a time, coefficients resident
+    z = O.bench_input_point(degree)
+    y = O.poly_evaluate(c, z)
+    proof = None
+    for k in (10, 100):
+        t0 = time.perf_counter()
+        for _ in range(k):
+            eng.open_submit(0, d, n, K.Scalar.from_limbs(z), K.Scalar.from_limbs(y))
+            proof = eng.wait(0)
+        open_lat = (time.perf_counter() - t0) / k
+    rc, q = O.quotient(c, z, y)
+    assert rc == 0
+    assert proof.compress() == O.p1_compress(O.commit_shortcut(q, secret))
     eng.dev_free(d)
     eng.close()
-    return reps / dt, lat * 1e3
+    return reps / dt, lat * 1e3, open_lat * 1e3
 
 
 if __name__ == "__main__":
     for degree in (100, 1000, 2500, 16384):
-        v, lat = run(degree)
-        print(json.dumps({"degree": degree, "commitments_per_s": round(v, 1), "single_commit_latency_ms": round(lat, 4)}), flush=True)
+        v, lat, open_lat = run(degree)
+        print(json.dumps({"degree": degree, "commitments_per_s": round(v, 1), "single_commit_latency_ms": round(lat, 4),
+                          "single_opening_proof_latency_ms": round(open_lat, 4)}), flush=True)
