@@ -293,17 +293,14 @@ static __device__ __noinline__ Fq fq_mul_quad_call(Fq a, Fq b) { return fq_mul(a
 #else
 #define KZG_QUAD_MUL(a, b) fq_mul(a, b)
 #endif
-__device__ __forceinline__ void xyzz30_add_quad(XYZZ30& acc, const XYZZ30& b, uint32_t q /* lane & 3 */) {
-    if (xyzz30_is_inf(b)) return;
-    if (xyzz30_is_inf(acc)) {
-        acc = b;
-        return;
-    }
+// the four stages; `live` = this quad's operands are two finite points (only then may it take the exceptional branch:
+// lanes that merely keep the wave busy carry zeros or stale values, whose P may well be zero)
+__device__ __forceinline__ void xyzz30_add_quad_core(XYZZ30& acc, const XYZZ30& b, uint32_t q /* lane & 3 */, bool live) {
     // stage 1
     Fq t = KZG_QUAD_MUL(fq_quad_select(q, acc.X, b.X, acc.Y, b.Y), fq_quad_select(q, b.ZZ, acc.ZZ, b.ZZZ, acc.ZZZ));
     const Fq U1 = fq_quad_broadcast<0>(t), U2 = fq_quad_broadcast<1>(t), S1 = fq_quad_broadcast<2>(t), S2 = fq_quad_broadcast<3>(t);
     const Fq P = fq_norm(fq_sub_raw(U2, U1)), R = fq_norm(fq_sub_raw(S2, S1));
-    if (fq_is_zero(P)) {
+    if (live && fq_is_zero(P)) {
         if (fq_is_zero(R)) xyzz30_dbl_inplace(acc);  // every lane doubles its copy
         else acc = xyzz30_inf();
         return;
@@ -323,42 +320,36 @@ __device__ __forceinline__ void xyzz30_add_quad(XYZZ30& acc, const XYZZ30& b, ui
     acc.Y = fq_norm(fq_sub_raw(fq_quad_broadcast<2>(t), fq_quad_broadcast<1>(t)));
     acc.X = X3;
 }
-#endif
-
-// XYZZ record in HBM (engine.h kXyzzBytes = 256): coordinate c (X, Y, ZZ, ZZZ) in words 16 c .. 16 c + 12
-#ifdef __HIPCC__
+__device__ __forceinline__ void xyzz30_add_quad(XYZZ30& acc, const XYZZ30& b, uint32_t q /* lane & 3 */) {
+    if (xyzz30_is_inf(b)) return;
+    if (xyzz30_is_inf(acc)) {
+        acc = b;
+        return;
+    }
+    xyzz30_add_quad_core(acc, b, q, true);
+}
 // The same for a wave in which only some quads have two finite operands.  Measured on MI355X (tools/microbench quad,
 // "tree_levels_us"): when the four waves of a workgroup run the addition with at most two quads (8 lanes) active
 // each, it takes 17-19 us instead of 5.5-6; with 16 or more active lanes per wave, or with a single wave running, it
-// does not.  So the quads that have nothing to add run the SAME instructions on two fixed operands (not curve points:
-// any two records with U2 != U1 take the generic path) and keep their own value: every lane of the wave stays active.
+// does not.  So the quads that have nothing to add run the SAME instructions on whatever they hold (zeros for infinity;
+// they never take the exceptional branch) and keep their own value: every lane of the wave stays active.
 // A wave in which no quad has anything to add skips the arithmetic altogether.
 __device__ __forceinline__ void xyzz30_add_quad_dense(XYZZ30& acc, const XYZZ30& b, uint32_t q /* lane & 3 */) {
     const bool binf = xyzz30_is_inf(b), ainf = xyzz30_is_inf(acc);
-    const bool real = !binf && !ainf;
-    if (__builtin_amdgcn_ballot_w64(real) == 0) {
+    const bool live = !binf && !ainf;
+    if (__builtin_amdgcn_ballot_w64(live) == 0) {
         if (ainf) acc = b;
         return;
     }
-    const Fq one = fq_one(), two = fq_add_raw(one, one);
-    XYZZ30 a2, b2;
-    Fq* fa[4] = {&a2.X, &a2.Y, &a2.ZZ, &a2.ZZZ};
-    Fq* fb[4] = {&b2.X, &b2.Y, &b2.ZZ, &b2.ZZZ};
-    const Fq* sa[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
-    const Fq* sb[4] = {&b.X, &b.Y, &b.ZZ, &b.ZZZ};
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-#pragma unroll
-        for (int i = 0; i < kQ; i++) {
-            fa[c]->d[i] = real ? sa[c]->d[i] : one.d[i];
-            fb[c]->d[i] = real ? sb[c]->d[i] : (c < 2 ? two.d[i] : one.d[i]);
-        }
-    xyzz30_add_quad(a2, b2, q);
+    XYZZ30 sum = acc;
+    xyzz30_add_quad_core(sum, b, q, live);  // idle quads: same instructions on whatever they hold (zeros at infinity)
     Fq* fo[4] = {&acc.X, &acc.Y, &acc.ZZ, &acc.ZZZ};
+    const Fq* fs[4] = {&sum.X, &sum.Y, &sum.ZZ, &sum.ZZZ};
+    const Fq* fb[4] = {&b.X, &b.Y, &b.ZZ, &b.ZZZ};
 #pragma unroll
     for (int c = 0; c < 4; c++)
 #pragma unroll
-        for (int i = 0; i < kQ; i++) fo[c]->d[i] = real ? fa[c]->d[i] : (ainf ? sb[c]->d[i] : fo[c]->d[i]);
+        for (int i = 0; i < kQ; i++) fo[c]->d[i] = live ? fs[c]->d[i] : (ainf ? fb[c]->d[i] : fo[c]->d[i]);
 }
 __device__ __forceinline__ Fq load_fq16(const uint4* __restrict__ p) {
     const uint4 a = p[0], b = p[1], c = p[2];
