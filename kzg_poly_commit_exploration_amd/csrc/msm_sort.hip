@@ -23,8 +23,12 @@ static uint32_t ilog2(uint32_t v) {
 MsmConfig choose_msm_config(size_t n, size_t table_budget_bytes) {
     // Scalars are first folded to |k| <= (r-1)/2 < 2^254 (sign moved onto the point), so signed digits never
     // carry out of bit 254.  The digit width c minimises
-    //     n * (digits per scalar)  (mixed additions)  +  8 * buckets  (bucket finalisation + reduction,
-    // weighted for the latency of the reduction levels).
+    //     n * (digits per scalar)  (mixed additions)  +  20 * buckets.
+    // A bucket costs the accumulation a run boundary (flush, walk to the next bucket: divergent) and the finalisation
+    // and reduction two general additions on latency-bound kernels.  The weight is fitted to measurements on MI355X
+    // (round 2, pipelined throughput, widths forced with KZG_MSM_C): 131073 terms x 8 polynomials per step 15 > 16 > 17
+    // (2772 / 2545 / 2362 per s), 262145 x 4: 15 = 16 > 17, 524289 x 2: 16 = 17, 2^20: 17 > 16 (408 / 394),
+    // 2^22: 19 > 20 (97.1 / 80.4) -- every one of them says 16 <= weight <= 32; round 1's 8 picked 16 / 17 / 17 / 17 / 20.
     //   windows: ceil(255/c) digits, 2^(c-1) buckets -> 17 bits / 15 windows / 65536 buckets at 2^20 points
     //   NAF:     255/(c+1) digits on average, 2^(c-2) buckets -> 19 bits / 13.1 digits / 131072 buckets
     // The NAF recoding is opt-in (KZG_MSM_RECODE=naf, and its 255-level table must fit the budget): measured on
@@ -41,13 +45,12 @@ MsmConfig choose_msm_config(size_t n, size_t table_budget_bytes) {
     double best = 1e300;
     for (uint32_t c = 8; c <= (naf ? 21u : 20u); c++) {
         if (fc >= 8 && fc <= (naf ? 21u : 20u) && c != fc) continue;
-        // Small jobs are latency-bound: a top window that holds only one or two bits of the (folded, < 2^254) scalars
-        // sends a half or a quarter of ALL points into one or two buckets, whose log-depth trees (50-80 us, measured
-        // at degree 1000 and 2500) then sit on the critical path.  Only widths whose top window keeps at least four
-        // bits are considered there: 8, 10, 13.
-        if (!naf && !fc && n <= 4096 && 254u - c * ((255 + c - 1) / c - 1) < 4u) continue;
+        // A top window that holds only one or two bits of the (folded, < 2^254) scalars sends a half or a quarter of ALL
+        // points into one or two buckets, whose log-depth trees then sit on the critical path of the job (50-80 us at
+        // degree 1000 / 2500, 0.1 ms at 2^14 with width 12 against 13).  Widths 9, 11, 12, 14 and 18 are not considered.
+        if (!naf && !fc && 254u - c * ((255 + c - 1) / c - 1) < 4u) continue;
         double cost = naf ? (double)n * (255.0 / (c + 1) + 0.5) + 8.0 * (double)(1u << (c - 2))
-                          : (double)n * ((255 + c - 1) / c) + 8.0 * (double)(1u << (c - 1));
+                          : (double)n * ((255 + c - 1) / c) + 20.0 * (double)(1u << (c - 1));
         if (cost < best) {
             best = cost;
             best_c = c;
