@@ -77,6 +77,7 @@ __global__ void KZG_ACCUM_ATTR __launch_bounds__(kAccumBlock, 2) k_bucket_accumu
 
     uint32_t b = bucket_of(offs, nb, start);
     uint32_t b_beg = offs[b], b_end = offs[b + 1];
+    uint32_t b_end_next = offs[(b + 2 <= nb) ? b + 2 : nb];
     uint32_t run_start = start;
     XYZZ30 acc = xyzz30_inf();
     // Software pipeline through LDS.  The point of reference e is consumed by the first two products of its addition
@@ -119,11 +120,17 @@ __global__ void KZG_ACCUM_ATTR __launch_bounds__(kAccumBlock, 2) k_bucket_accumu
             uint4* dst = (run_start == b_beg) ? buckets + (size_t)b * kXyzzU4 : part_a + (size_t)lane * kXyzzU4;
             store_xyzz30(dst, acc);  // a run that began inside the bucket necessarily began at `start`
             acc = xyzz30_inf();
-            do {
+            // the end of the next bucket was read one boundary ago: the walk does not wait for memory unless it has
+            // to skip empty buckets
+            b++;
+            b_beg = b_end;
+            b_end = b_end_next;
+            while (b_end <= e) {
                 b++;
                 b_beg = b_end;
                 b_end = offs[b + 1];
-            } while (b_end <= e);
+            }
+            b_end_next = offs[(b + 2 <= nb) ? b + 2 : nb];
             run_start = e;
         }
         Fq P, R;
