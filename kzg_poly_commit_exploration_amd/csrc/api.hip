@@ -389,7 +389,7 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
             HIP_TRY(ctx, hipStreamWaitEvent(st, s.accum_ev, 0));
         }
         launch_bucket_finalize(st, s.d_offs, nbt, lanes, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_ws, s.d_small + 26,
-                               finalize_group_size(nbt), false);
+                               finalize_group_size(nbt));
         // (gating the finalisation as well measured 3-5 % slower: it is short and wants to run at once)
         if (ctx->gate_lds_bytes && !alone) hipLaunchKernelGGL(k_reduce_gate, dim3(1), dim3(64), ctx->gate_lds_bytes, st, (uint32_t*)nullptr);
         launch_tree_sums_two_stage(st, stage1, 2, stage2, 4, (uint32_t*)s.d_heavy_ws + 64);

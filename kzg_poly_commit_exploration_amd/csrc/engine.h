@@ -87,12 +87,10 @@ void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t
 // counters) the caller has zeroed -- ahead of time, so that nothing sits between the end of the accumulation
 // and this launch (a fill kernel there lets the next slot's accumulation take the chip first: +0.9 ms)
 size_t heavy_workspace_bytes();
-// group: quads per bucket (finalize_group_size(nb); 1 = one quad per bucket, the throughput form); write_empty: empty
-// buckets are written as infinity by the kernel (the caller then skips the memset of d_buckets).
+// group: quads per bucket (finalize_group_size(nb); 1 = one quad per bucket, the throughput form).
 void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t lanes, const void* d_part_a,
                             const void* d_part_b, void* d_buckets, void* d_heavy_ws,
-                            uint32_t* d_refs_out /* receives the number of references, may be null */, uint32_t group = 1,
-                            bool write_empty = false);
+                            uint32_t* d_refs_out /* receives the number of references, may be null */, uint32_t group = 1);
 uint32_t finalize_group_size(uint32_t nb);
 // Small jobs (at most kTinyRefs references, one polynomial): accumulation, finalisation, long-bucket trees and both
 // reduction stages in ONE launch (msm_finalize.hip: k_small_msm).  The first kHeavyHeaderBytes of d_heavy_ws must be zero.

@@ -284,9 +284,8 @@ __device__ __forceinline__ Fq fq_quad_broadcast(const Fq& v) {  // lane SRC of e
     }
     return r;
 }
-// KZG_QUAD_MUL_CALLS: the four products of a cooperative addition as calls of ONE copy of the multiplier per kernel
-// (operands and result in registers).  The kernels that use it run each addition site a handful of times per launch:
-// what they wait for is the instruction fetch of code they have never executed, and an inlined addition is 40 KB of it.
+// (A/B switch KZG_QUAD_MUL_CALLS: the four products as calls of ONE copy of the multiplier per kernel instead of four
+// inlined ones -- a tenth of the code to fetch on first execution, but 2-10 % more latency at degree 100 ... 2^14.)
 #ifdef KZG_QUAD_MUL_CALLS
 static __device__ __noinline__ Fq fq_mul_quad_call(Fq a, Fq b) { return fq_mul(a, b); }
 #define KZG_QUAD_MUL(a, b) fq_mul_quad_call(a, b)

@@ -126,8 +126,7 @@ __global__ void __launch_bounds__(64 * kCoop, KZG_TREE_WAVES) k_bucket_finalize(
 // With few buckets (up to 16384: commitments of up to ~2^15 terms) the serial loop of k_bucket_finalize is the
 // longest chain of the job.  k_bucket_finalize_group gives every bucket `group` quads (a power of two <= 16, workgroup
 // = 64 quads): each adds every group-th piece, then the group folds through LDS -- pieces/group + log2(group) dependent
-// additions instead of one per piece.  Buckets beyond 8 pieces per quad still go to the long-bucket trees.  Empty
-// buckets can be written as infinity here (write_empty), which saves the caller the memset of the bucket array.
+// additions instead of one per piece.  Buckets beyond 8 pieces per quad still go to the long-bucket trees.
 // Small jobs (<= 65536 references) run the same steps as phases of ONE launch: k_small_msm below.
 __device__ __forceinline__ uint32_t bucket_of_pos(const uint32_t* __restrict__ offs, uint32_t nb, uint32_t pos) {
     uint32_t lo = 0, hi = nb;  // invariant: offs[lo] <= pos, (hi == nb or offs[hi] > pos)
@@ -152,7 +151,7 @@ constexpr uint32_t kGroupSerial = 8;  // pieces per quad before a bucket goes to
 __global__ void __launch_bounds__(64 * kCoop, KZG_TREE_WAVES) k_bucket_finalize_group(
     const uint32_t* __restrict__ offs, uint32_t nb, uint32_t lanes, const uint4* __restrict__ part_a,
     const uint4* __restrict__ part_b, uint4* __restrict__ buckets, HeavyWs ws, uint32_t* __restrict__ refs_out,
-    uint32_t group, uint32_t write_empty) {
+    uint32_t group) {
     __shared__ uint32_t lds[4 * kQ * 64];
     const uint32_t t = threadIdx.x / kCoop;  // logical lane 0..63
     const bool lead = (threadIdx.x & 3u) == 0;
@@ -165,9 +164,7 @@ __global__ void __launch_bounds__(64 * kCoop, KZG_TREE_WAVES) k_bucket_finalize_
     if (b < nb) {
         const uint32_t L = accumulate_seg_len(offs[nb], lanes);
         const uint32_t s = offs[b], e = offs[b + 1];
-        if (s == e) {
-            if (write_empty && l == 0 && lead) store_xyzz30(buckets + (size_t)b * kXyzzU4, xyzz30_inf());
-        } else {
+        if (s != e) {  // (empty buckets stay at infinity: the array was zeroed)
             l_lo = s / L;
             const uint32_t l_hi = (e - 1) / L;
             if (l_lo != l_hi) {  // (inside one segment: written complete by the accumulation kernel)
@@ -553,16 +550,15 @@ __global__ void __launch_bounds__(64 * kCoop, 1) k_small_msm(SmallJob job) {
 }
 
 void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t lanes, const void* d_part_a,
-                            const void* d_part_b, void* d_buckets, void* d_heavy_ws, uint32_t* d_refs_out, uint32_t group,
-                            bool write_empty) {
+                            const void* d_part_b, void* d_buckets, void* d_heavy_ws, uint32_t* d_refs_out, uint32_t group) {
     HeavyWs ws = carve(d_heavy_ws);
     const uint4* pa = reinterpret_cast<const uint4*>(d_part_a);
     const uint4* pb = reinterpret_cast<const uint4*>(d_part_b);
     uint4* bk = reinterpret_cast<uint4*>(d_buckets);
-    if (group >= 2 || write_empty) {
+    if (group >= 2) {
         const uint32_t per_block = 64 / group;
         hipLaunchKernelGGL(k_bucket_finalize_group, dim3((nb + per_block - 1) / per_block), dim3(64 * kCoop), 0, s, d_offs, nb,
-                           lanes, pa, pb, bk, ws, d_refs_out, group, write_empty ? 1u : 0u);
+                           lanes, pa, pb, bk, ws, d_refs_out, group);
     } else {
         hipLaunchKernelGGL(k_bucket_finalize, dim3((nb + 63) / 64), dim3(64 * kCoop), 0, s, d_offs, nb, lanes, pa, pb, bk, ws, d_refs_out);
     }

@@ -10,7 +10,8 @@ FLAGS="-DKZG_LAZY_FP -DKZG_FIPS_SQR -O1 -g -fPIC --offload-arch=gfx950 -std=c++1
 hipcc $FLAGS -fsanitize=address -fno-gpu-sanitize -c kzg_poly_commit_exploration_amd/csrc/api.hip -o "$OUT/api.o"
 B=kzg_poly_commit_exploration_amd/csrc/build
 hipcc --offload-arch=gfx950 -shared -fPIC -pthread -fsanitize=address -shared-libsan -o "$OUT/libkzg_asan.so" "$OUT/api.o" \
-  $B/msm_sort.o $B/msm_accum.o $B/msm_finalize.o $B/msm_reduce.o $B/poly_kernels.o $B/srs_kernels.o
+  $B/msm_sort.o $B/msm_accum.o $B/msm_finalize.o $B/msm_reduce.o $B/poly_kernels.o $B/srs_kernels.o $B/multi.o $B/srs_io.o \
+  -L/opt/rocm/lib -lrccl
 RT=$(/opt/rocm/lib/llvm/bin/clang -print-file-name=libclang_rt.asan-x86_64.so)
 ASAN_OPTIONS=detect_leaks=0:verify_asan_link_order=0 LD_PRELOAD=$RT KZG_MI355X_LIB="$OUT/libkzg_asan.so" \
   python -m pytest tests/test_verify.py tests/test_abi.py -x -q
