@@ -374,9 +374,11 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], st));
     } else {
         HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)nbt * kXyzzBytes, st));  // zero = infinity
-        // hand over to the shared accumulation stream and back
-        hipStream_t hs = ctx->serialize_accum ? ctx->heavy_stream : st;
-        if (ctx->serialize_accum) {
+        // hand over to the shared accumulation stream and back (each hand-over costs ~12 us: not when no other slot
+        // has work whose accumulation this one could collide with)
+        const bool hand_over = ctx->serialize_accum && !alone;
+        hipStream_t hs = hand_over ? ctx->heavy_stream : st;
+        if (hand_over) {
             HIP_TRY(ctx, hipEventRecord(s.sorted_ev, st));
             HIP_TRY(ctx, hipStreamWaitEvent(hs, s.sorted_ev, 0));
         }
@@ -384,7 +386,7 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         launch_bucket_accumulate(hs, ctx->d_table, s.d_sorted, s.d_offs, nbt, lanes, s.d_buckets, s.d_part_a, s.d_part_b,
                                  ctx->accum_lds_bytes, s.d_pair_scratch, max_refs);
         if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], hs));
-        if (ctx->serialize_accum) {
+        if (hand_over) {
             HIP_TRY(ctx, hipEventRecord(s.accum_ev, hs));
             HIP_TRY(ctx, hipStreamWaitEvent(st, s.accum_ev, 0));
         }

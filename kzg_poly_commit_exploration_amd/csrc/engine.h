@@ -113,7 +113,7 @@ struct TreeSumDesc {
     uint32_t inner;    // groups per outer block (= groups when there is no batch dimension)
     uint64_t ostride;  // record stride between outer blocks
 };
-void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count);
+void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count, bool dense = false);
 // stage2 reads what stage1 wrote.  One launch when both stages fit the chip at once (d_sync: two zeroed words, e.g.
 // words 4 and 5 of d_heavy_ws), otherwise two launches.
 void launch_tree_sums_two_stage(hipStream_t s, const TreeSumDesc* stage1, uint32_t count1, const TreeSumDesc* stage2,

@@ -147,7 +147,12 @@ __device__ __forceinline__ XYZZ30 load_table_point(const uint4* __restrict__ tab
     r.ZZZ = r.ZZ;
     return r;
 }
-constexpr uint32_t kGroupSerial = 8;  // pieces per quad before a bucket goes to the long-bucket trees instead
+constexpr uint32_t kGroupSerial = 8;  // pieces per quad before a bucket goes to the long-bucket trees instead ...
+// ... but never fewer than one chunk of those trees in all: at 2^16 terms (4096 buckets of ~32 pieces, four quads each)
+// a limit of 32 sent every second bucket there (235 us)
+__host__ __device__ inline uint32_t group_span_limit(uint32_t group) {
+    return kGroupSerial * group > (uint32_t)kChunk ? kGroupSerial * group : (uint32_t)kChunk;
+}
 __global__ void __launch_bounds__(64 * kCoop, KZG_TREE_WAVES) k_bucket_finalize_group(
     const uint32_t* __restrict__ offs, uint32_t nb, uint32_t lanes, const uint4* __restrict__ part_a,
     const uint4* __restrict__ part_b, uint4* __restrict__ buckets, HeavyWs ws, uint32_t* __restrict__ refs_out,
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__(64 * kCoop, KZG_TREE_WAVES) k_bucket_finalize_
             if (l_lo != l_hi) {  // (inside one segment: written complete by the accumulation kernel)
                 span = l_hi - l_lo + 1;
                 first_is_b = s != l_lo * L;
-                if (span > kGroupSerial * group) {
+                if (span > group_span_limit(group)) {
                     if (l == 0 && lead) {
                         HeavyEntry en;
                         en.bucket = b; en.l_lo = l_lo; en.span = span; en.first_is_b = first_is_b ? 1u : 0u;
@@ -436,7 +441,7 @@ __global__ void __launch_bounds__(64 * kCoop, 1) k_small_msm(SmallJob job) {
                         if (l_lo != l_hi) {  // (inside one segment: written complete by phase A)
                             const uint32_t span = l_hi - l_lo + 1;
                             const bool first_is_b = s != l_lo * L;
-                            if (span > kGroupSerial * gsz) {
+                            if (span > group_span_limit(gsz)) {
                                 if (l == 0 && lead) {
                                     HeavyEntry en;
                                     en.bucket = bk; en.l_lo = l_lo; en.span = span; en.first_is_b = first_is_b ? 1u : 0u;
@@ -566,10 +571,11 @@ void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, 
 }
 
 uint32_t finalize_group_size(uint32_t nb) {
-    // as many quads per bucket as one resident round of 512 workgroups (two per CU) offers, 16 at most; one quad per
-    // bucket (the throughput form, k_bucket_finalize) from 32768 buckets on
+    // as many quads per bucket as ONE workgroup per CU offers (256 x 64 quads), 16 at most: a second workgroup on a CU
+    // halves the speed of both, which costs more than the shorter chain of a larger group saves (2^17 terms, 16384
+    // buckets of ~8 pieces: 85 us with two quads per bucket on 512 workgroups)
     uint32_t g = 1;
-    while (g < 16 && (uint64_t)nb * g * 2 <= 32768) g <<= 1;
+    while (g < 16 && (uint64_t)nb * g * 2 <= 16384) g <<= 1;
     return g;
 }
 

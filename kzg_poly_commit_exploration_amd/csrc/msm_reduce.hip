@@ -41,6 +41,9 @@ struct TreeJobs {
     uint32_t* sync;
 };
 
+// kDense: idle quads keep their lanes active (xyzz30_add_quad_dense, g1_30.hip.h) -- the latency form, chosen for jobs of
+// at most 16384 buckets; above that the trees share the chip with other slots' accumulation kernels and stay sparse.
+template <bool kDense>
 __global__ void __launch_bounds__(kTreeBlock, KZG_TREE_WAVES) k_tree_sum(TreeJobs jobs) {
     constexpr int kLogical = kTreeBlock / kCoop;  // logical lanes per workgroup
     __shared__ uint32_t lds[4 * kQ * kLogical];
@@ -73,7 +76,8 @@ __global__ void __launch_bounds__(kTreeBlock, KZG_TREE_WAVES) k_tree_sum(TreeJob
         const uint64_t base = (uint64_t)(g / J.inner) * J.ostride + (uint64_t)(g % J.inner) * J.gstride;
         for (uint32_t q = l; q < J.len; q += lanes_per_group) {
             XYZZ30 b = load_xyzz30(J.in + (size_t)(base + q * J.estride) * kXyzzU4);
-            KZG_TREE_ADD(acc, b);
+            if (kDense) xyzz30_add_quad_dense(acc, b, threadIdx.x & 3u);
+            else KZG_TREE_ADD(acc, b);
         }
     }
     for (uint32_t off = lanes_per_group >> 1; off >= 1; off >>= 1) {
@@ -86,7 +90,17 @@ __global__ void __launch_bounds__(kTreeBlock, KZG_TREE_WAVES) k_tree_sum(TreeJob
                 for (int i = 0; i < kQ; i++) lds[(q * kQ + i) * kLogical + (t - off)] = (uint32_t)f[q]->d[i];
         }
         __syncthreads();
-        if (l < off) {
+        if (kDense) {  // every quad enters; those without a partner bring an operand at infinity
+            XYZZ30 o = xyzz30_inf();
+            if (l < off) {
+                Fq* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int i = 0; i < kQ; i++) f[q]->d[i] = (int32_t)lds[(q * kQ + i) * kLogical + t];
+            }
+            xyzz30_add_quad_dense(acc, o, threadIdx.x & 3u);
+        } else if (l < off) {
             XYZZ30 o;
             Fq* f[4] = {&o.X, &o.Y, &o.ZZ, &o.ZZZ};
 #pragma unroll
@@ -108,7 +122,13 @@ static uint32_t plan_jobs(TreeJobs& jobs, uint32_t first, const TreeSumDesc* des
     return plan_tree_jobs(jobs.j + first, descs, count, first_block, KZG_TREE_WAVES);
 }
 
-void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count) {
+static bool dense_trees(const TreeSumDesc* descs, uint32_t count) {
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < count; i++) total += (uint64_t)descs[i].groups * descs[i].len;
+    return total <= 2 * 16384;  // (stage 1 sums every bucket twice: rows and columns)
+}
+
+void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count, bool dense) {
     if (count > 6) count = 6;
     TreeJobs jobs;
     jobs.count = count;
@@ -116,7 +136,8 @@ void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count) {
     jobs.sync = nullptr;
     const uint32_t blocks = plan_jobs(jobs, 0, descs, count, 0);
     if (!blocks) return;
-    hipLaunchKernelGGL(k_tree_sum, dim3(blocks), dim3(kTreeBlock), 0, s, jobs);
+    if (dense) hipLaunchKernelGGL(k_tree_sum<true>, dim3(blocks), dim3(kTreeBlock), 0, s, jobs);
+    else hipLaunchKernelGGL(k_tree_sum<false>, dim3(blocks), dim3(kTreeBlock), 0, s, jobs);
 }
 
 void launch_tree_sums_two_stage(hipStream_t s, const TreeSumDesc* stage1, uint32_t count1, const TreeSumDesc* stage2,
@@ -126,14 +147,16 @@ void launch_tree_sums_two_stage(hipStream_t s, const TreeSumDesc* stage1, uint32
     const uint32_t b1 = count1 + count2 <= 6 ? plan_jobs(jobs, 0, stage1, count1, 0) : 0;
     const uint32_t b2 = b1 ? plan_jobs(jobs, count1, stage2, count2, b1) : 0;
     // one launch only while every workgroup is resident at once anyway (two per CU); else two launches
+    const bool dense = dense_trees(stage1, count1);
     if (!d_sync || !b1 || !b2 || b1 + b2 > 512) {
-        launch_tree_sums(s, stage1, count1);
-        launch_tree_sums(s, stage2, count2);
+        launch_tree_sums(s, stage1, count1, dense);
+        launch_tree_sums(s, stage2, count2, dense);
         return;
     }
     jobs.stage1_blocks = b1;
     jobs.sync = d_sync;
-    hipLaunchKernelGGL(k_tree_sum, dim3(b1 + b2), dim3(kTreeBlock), 0, s, jobs);
+    if (dense) hipLaunchKernelGGL(k_tree_sum<true>, dim3(b1 + b2), dim3(kTreeBlock), 0, s, jobs);
+    else hipLaunchKernelGGL(k_tree_sum<false>, dim3(b1 + b2), dim3(kTreeBlock), 0, s, jobs);
 }
 
 }  // namespace kzg
