@@ -405,16 +405,16 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
 
 // host tail.  With V indexed by u = u1 * 2^lo + u0:  sum_u u V_u = 2^lo * wsum(R2) + wsum(C2), where
 // R2[u1] = sum_u0 V, C2[u0] = sum_u1 V and wsum(P) = sum_v v * P_v (running sums, <= 32 entries).
-hf::P1 host_wsum(const uint64_t* recs, uint32_t len) {
-    hf::P1 run = hf::p1_inf(), acc = hf::p1_inf();
+hf::PX host_wsum(const uint64_t* recs, uint32_t len) {
+    hf::PX run = hf::px_inf(), acc = hf::px_inf();
     for (uint32_t v = len; v-- > 1;) {
-        run = hf::p1_add(run, hf::p1_from_xyzz(recs + (size_t)v * kXyzzWords64));
-        acc = hf::p1_add(acc, run);
+        run = hf::px_add(run, hf::px_from_record(recs + (size_t)v * kXyzzWords64));
+        acc = hf::px_add(acc, run);
     }
     return acc;
 }
-hf::P1 host_shift(hf::P1 p, uint32_t k) {
-    for (uint32_t i = 0; i < k; i++) p = hf::p1_double(p);
+hf::PX host_shift(hf::PX p, uint32_t k) {
+    for (uint32_t i = 0; i < k; i++) p = hf::px_double(p);
     return p;
 }
 hf::P1 finish_msm(const kzg_ctx* ctx, const Slot& s, uint32_t p = 0, uint32_t batch = 1) {
@@ -424,15 +424,15 @@ hf::P1 finish_msm(const kzg_ctx* ctx, const Slot& s, uint32_t p = 0, uint32_t ba
     auto at = [&](uint32_t off, uint32_t len) { return f + ((size_t)off * batch + (size_t)p * len) * kXyzzWords64; };
     const uint32_t rh = 1u << P.row_hi, rl = 1u << P.row_lo, ch = 1u << P.col_hi, cl = 1u << P.col_lo;
     // W(Row) = 2^row_lo * wsum(R2row) + wsum(C2row);  W(Col) likewise
-    hf::P1 w_row = hf::p1_add(host_shift(host_wsum(at(P.off_r2row, rh), rh), P.row_lo), host_wsum(at(P.off_c2row, rl), rl));
-    hf::P1 w_col = hf::p1_add(host_shift(host_wsum(at(P.off_r2col, ch), ch), P.col_lo), host_wsum(at(P.off_c2col, cl), cl));
+    hf::PX w_row = hf::px_add(host_shift(host_wsum(at(P.off_r2row, rh), rh), P.row_lo), host_wsum(at(P.off_c2row, rl), rl));
+    hf::PX w_col = hf::px_add(host_shift(host_wsum(at(P.off_r2col, ch), ch), P.col_lo), host_wsum(at(P.off_c2col, cl), cl));
     // sum_b b B_b = C * W(Row) + W(Col);  sum_b B_b = sum of R2row.
     // Bucket b weighs b + 1 (windows: digit magnitude) or 2b + 1 (NAF: odd digits only).
-    hf::P1 total = hf::p1_add(host_shift(w_row, P.lo_bits), w_col);
-    if (ctx->cfg.recode == kRecodeNaf) total = hf::p1_double(total);
+    hf::PX total = hf::px_add(host_shift(w_row, P.lo_bits), w_col);
+    if (ctx->cfg.recode == kRecodeNaf) total = hf::px_double(total);
     const uint64_t* r2 = at(P.off_r2row, rh);
-    for (uint32_t k = 0; k < rh; k++) total = hf::p1_add(total, hf::p1_from_xyzz(r2 + (size_t)k * kXyzzWords64));
-    return hf::p1_normalize(total);
+    for (uint32_t k = 0; k < rh; k++) total = hf::px_add(total, hf::px_from_record(r2 + (size_t)k * kXyzzWords64));
+    return hf::px_normalize(total);
 }
 
 void write_p1(uint64_t out[18], const hf::P1& p) { std::memcpy(out, &p, sizeof p); }

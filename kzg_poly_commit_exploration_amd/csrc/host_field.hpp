@@ -103,7 +103,7 @@ inline Fp mul_wide(const Fp& a, const Fp& b) {
 }
 // a, b < p.  p < 2^383 leaves the top bit of every partial sum free, so the two carry words of the general routine
 // disappear (the "no-carry" CIOS): each round is two interleaved multiply-accumulate chains over six limbs.
-inline Fp operator*(const Fp& a, const Fp& b) {
+inline Fp mul_portable(const Fp& a, const Fp& b) {
     uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
     for (int i = 0; i < 6; ++i) {
         const uint64_t bi = b.l[i];
@@ -132,6 +132,45 @@ inline Fp operator*(const Fp& a, const Fp& b) {
     const Fp s = raw_sub(r, kP, br);
     return br ? r : s;
 }
+#if defined(__x86_64__)
+// The same rounds with mulx and the two independent carry chains of adcx / adox (BMI2 + ADX, checked once at run
+// time): t[0..6] += v[0..5] * x per row, first with the row of a, then with the row of p.  ~20 % faster than what the
+// compilers make of the portable form; the host tail of a commitment is 400 ... 2000 of these products.
+#define KZG_HOST_MAC_ROW(v, x)                                                                                   \
+    asm("xorl %k[lo], %k[lo]\n\t"                                                                                 \
+        "mulxq 0(%[vp]), %[lo], %[hi]\n\t adcxq %[lo], %[t0]\n\t adoxq %[hi], %[t1]\n\t"                        \
+        "mulxq 8(%[vp]), %[lo], %[hi]\n\t adcxq %[lo], %[t1]\n\t adoxq %[hi], %[t2]\n\t"                        \
+        "mulxq 16(%[vp]), %[lo], %[hi]\n\t adcxq %[lo], %[t2]\n\t adoxq %[hi], %[t3]\n\t"                       \
+        "mulxq 24(%[vp]), %[lo], %[hi]\n\t adcxq %[lo], %[t3]\n\t adoxq %[hi], %[t4]\n\t"                       \
+        "mulxq 32(%[vp]), %[lo], %[hi]\n\t adcxq %[lo], %[t4]\n\t adoxq %[hi], %[t5]\n\t"                       \
+        "mulxq 40(%[vp]), %[lo], %[hi]\n\t adcxq %[lo], %[t5]\n\t adoxq %[hi], %[t6]\n\t"                       \
+        "movl $0, %k[lo]\n\t adcxq %[lo], %[t6]\n\t"                                                             \
+        : [t0] "+r"(t0), [t1] "+r"(t1), [t2] "+r"(t2), [t3] "+r"(t3), [t4] "+r"(t4), [t5] "+r"(t5), [t6] "+r"(t6),   \
+          [lo] "=&r"(lo), [hi] "=&r"(hi)                                                                         \
+        : [vp] "r"(v), "d"(x), "m"(*(const uint64_t(*)[6])(v))                                                    \
+        : "cc")
+__attribute__((target("bmi2,adx"))) inline Fp mul_adx(const Fp& a, const Fp& b) {
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0, lo, hi;
+    for (int i = 0; i < 6; ++i) {
+        KZG_HOST_MAC_ROW(a.l, b.l[i]);
+        const uint64_t m = t0 * kN0;
+        KZG_HOST_MAC_ROW(kP.l, m);  // t0 becomes 0: drop it
+        t0 = t1; t1 = t2; t2 = t3; t3 = t4; t4 = t5; t5 = t6; t6 = 0;
+    }
+    const Fp r = {{t0, t1, t2, t3, t4, t5}};
+    uint64_t br;
+    const Fp s = raw_sub(r, kP, br);
+    return br ? r : s;
+}
+#undef KZG_HOST_MAC_ROW
+inline bool cpu_has_adx() {
+    static const bool yes = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+    return yes;
+}
+inline Fp operator*(const Fp& a, const Fp& b) { return cpu_has_adx() ? mul_adx(a, b) : mul_portable(a, b); }
+#else
+inline Fp operator*(const Fp& a, const Fp& b) { return mul_portable(a, b); }
+#endif
 inline Fp sqr(const Fp& a) { return a * a; }
 inline Fp inv_fermat(const Fp& a) {  // a^(p-2): ~570 products; kept as the cross-check of inv() in tests/host
     Fp e = kP;
@@ -258,6 +297,64 @@ inline P1 p1_from_xyzz(const uint64_t* w) {
     r.z = ZZ;
     return r;
 }
+// ---- the host tail of an MSM in the device's own coordinates ----------------------------------------------------
+// The partial sums arrive as XYZZ records (x = X / ZZ, y = Y / ZZZ).  Adding them as they are costs 12M + 2S per general
+// addition against 11M + 5S in Jacobian form, and saves the two products per record of the conversion: ~20 % fewer
+// base-field products for the 30 ... 130 additions of a commitment's tail.
+struct PX {
+    Fp x, y, zz, zzz;
+    bool is_inf() const { return zz.is_zero(); }
+};
+inline PX px_inf() {
+    PX r;
+    std::memset(&r, 0, sizeof r);
+    return r;
+}
+inline PX px_from_record(const uint64_t* w) {
+    const int32_t* d = reinterpret_cast<const int32_t*>(w);
+    PX r;
+    r.zz = fp_from_digits30(d + 32);
+    if (r.zz.is_zero()) return px_inf();
+    r.x = fp_from_digits30(d);
+    r.y = fp_from_digits30(d + 16);
+    r.zzz = fp_from_digits30(d + 48);
+    return r;
+}
+inline PX px_double(const PX& p) {  // dbl-2008-s-1 (a = 0)
+    if (p.is_inf() || p.y.is_zero()) return px_inf();
+    const Fp u = p.y + p.y, v = sqr(u), w = u * v, s = p.x * v;
+    const Fp xx = sqr(p.x), m = xx + xx + xx;
+    PX r;
+    r.x = sqr(m) - s - s;
+    r.y = m * (s - r.x) - w * p.y;
+    r.zz = v * p.zz;
+    r.zzz = w * p.zzz;
+    return r;
+}
+inline PX px_add(const PX& a, const PX& b) {  // add-2008-s, complete: handles inf, a == b, a == -b
+    if (a.is_inf()) return b;
+    if (b.is_inf()) return a;
+    const Fp u1 = a.x * b.zz, u2 = b.x * a.zz, s1 = a.y * b.zzz, s2 = b.y * a.zzz;
+    const Fp pp = u2 - u1, rr = s2 - s1;
+    if (pp.is_zero()) return rr.is_zero() ? px_double(a) : px_inf();
+    const Fp p2 = sqr(pp), p3 = pp * p2, q = u1 * p2;
+    PX r;
+    r.x = sqr(rr) - p3 - q - q;
+    r.y = rr * (q - r.x) - s1 * p3;
+    r.zz = a.zz * b.zz * p2;
+    r.zzz = a.zzz * b.zzz * p3;
+    return r;
+}
+inline P1 px_normalize(const PX& p) {  // affine with z = R, or all-zero for inf: one inversion for both denominators
+    if (p.is_inf()) return p1_inf();
+    const Fp i = inv(p.zz * p.zzz);
+    P1 r;
+    r.x = p.x * (i * p.zzz);
+    r.y = p.y * (i * p.zz);
+    r.z = kOne;
+    return r;
+}
+
 inline void p1_compress(uint8_t out[48], const P1& p) {  // ZCash encoding (reference src/curves.rs:99-110)
     if (p.is_inf()) {
         std::memset(out, 0, 48);

@@ -197,6 +197,13 @@ void hf_mul(const uint64_t* a, const uint64_t* b, uint64_t* r) {
     const kzg_host::Fp z = x * y;
     memcpy(r, z.l, 48);
 }
+void hf_mul_portable(const uint64_t* a, const uint64_t* b, uint64_t* r) {
+    kzg_host::Fp x, y;
+    memcpy(x.l, a, 48);
+    memcpy(y.l, b, 48);
+    const kzg_host::Fp z = kzg_host::mul_portable(x, y);
+    memcpy(r, z.l, 48);
+}
 void hf_mul_wide(const uint64_t* a, const uint64_t* b, uint64_t* r) {
     kzg_host::Fp x, y;
     memcpy(x.l, a, 48);
@@ -214,5 +221,22 @@ void hf_inv(const uint64_t* a, uint64_t* r, uint64_t* r_fermat) {
 void hf_from_digits30(const int32_t* d, uint64_t* r) {
     const kzg_host::Fp z = kzg_host::fp_from_digits30(d);
     memcpy(r, z.l, 48);
+}
+
+// host tail in XYZZ coordinates (host_field.hpp: px_*): records are 64 x int32 as the device writes them (coordinate c at
+// words 16 c).  out = affine Montgomery x (6 words), y (6 words), flag 1 = infinity
+static void put_p1(const kzg_host::P1& r, uint64_t* out) {
+    memcpy(out, r.x.l, 48);
+    memcpy(out + 6, r.y.l, 48);
+    out[12] = r.is_inf() ? 1 : 0;
+}
+void hf_px_sum(const int32_t* rec_a, const int32_t* rec_b, uint64_t* out_add, uint64_t* out_dbl, uint64_t* out_wsum3) {
+    const kzg_host::PX a = kzg_host::px_from_record((const uint64_t*)rec_a), b = kzg_host::px_from_record((const uint64_t*)rec_b);
+    put_p1(kzg_host::px_normalize(kzg_host::px_add(a, b)), out_add);
+    put_p1(kzg_host::px_normalize(kzg_host::px_double(a)), out_dbl);
+    // a + 2b + 3(a + b) through repeated additions of already added values (denominators far from 1)
+    kzg_host::PX s = kzg_host::px_add(a, b), t = kzg_host::px_add(kzg_host::px_add(s, s), s);
+    t = kzg_host::px_add(t, kzg_host::px_add(a, kzg_host::px_double(b)));
+    put_p1(kzg_host::px_normalize(t), out_wsum3);
 }
 }

@@ -382,7 +382,9 @@ def test_host_field_products_and_inverse(lib):
         a = edge[k % len(edge)] if k < 24 else rng.randrange(P)
         b = edge[(k // len(edge)) % len(edge)] if k < 24 else rng.randrange(P)
         r = U6()
-        lib.hf_mul(_limbs(a), _limbs(b), r)
+        lib.hf_mul(_limbs(a), _limbs(b), r)  # mulx / adcx / adox rows where the CPU has them
+        assert _int6(r) == a * b * rinv % P
+        lib.hf_mul_portable(_limbs(a), _limbs(b), r)
         assert _int6(r) == a * b * rinv % P
         wide = rng.randrange(1 << 384)  # any 384-bit left operand
         lib.hf_mul_wide(_limbs(wide), _limbs(b), r)
@@ -401,3 +403,54 @@ def test_host_field_products_and_inverse(lib):
         v = rng.randrange(-3 * P, 3 * P)  # |v| < 3.5 p as the kernels leave it
         lib.hf_from_digits30(I13(*balanced(v)), r)
         assert _int6(r) == v * pow(1 << 6, -1, P) % P
+
+
+def test_host_tail_in_xyzz_coordinates(lib):
+    """host_field.hpp px_add / px_double / px_normalize (the host tail of every commitment works on the device's XYZZ
+    records directly): against textbook affine arithmetic, through infinity, equal and opposite operands"""
+    gx = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+    gy = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+    G = (gx, gy)
+    pts = [G]
+    for _ in range(11):
+        pts.append(_ec_add(pts[-1], G))
+    I52, I64, U13 = ctypes.c_int32 * 52, ctypes.c_int32 * 64, ctypes.c_uint64 * 13
+    rng = random.Random(41)
+
+    def build(ks):
+        acc, want = I52(), None
+        for idx, neg in ks:
+            px, py = _affine(pts[idx])
+            lib.f30_madd(acc, I13(*px), I13(*py), neg)
+            want = _ec_add(want, pts[idx] if not neg else (pts[idx][0], (-pts[idx][1]) % P))
+        rec = I64()
+        for c in range(4):
+            for i in range(13):
+                rec[16 * c + i] = acc[13 * c + i]
+        return rec, want
+
+    def mul(k, pt):
+        r = None
+        for _ in range(k):
+            r = _ec_add(r, pt)
+        return r
+
+    def got(out):
+        if out[12]:
+            return None
+        rinv = pow(R384, -1, P)
+        return _int6(out[0:6]) * rinv % P, _int6(out[6:12]) * rinv % P
+
+    cases = [([(0, 0), (1, 0)], [(2, 0)]), ([(0, 0), (1, 0)], [(2, 1)]), ([], [(4, 0)]), ([(4, 0)], []), ([], [])]
+    for _ in range(40):
+        cases.append(([(rng.randrange(12), rng.randrange(2)) for _ in range(rng.randrange(1, 5))],
+                      [(rng.randrange(12), rng.randrange(2)) for _ in range(rng.randrange(1, 5))]))
+    for ka, kb in cases:
+        a, wa = build(ka)
+        b, wb = build(kb)
+        o_add, o_dbl, o_w = U13(), U13(), U13()
+        lib.hf_px_sum(a, b, o_add, o_dbl, o_w)
+        assert got(o_add) == _ec_add(wa, wb), (ka, kb)
+        assert got(o_dbl) == _ec_add(wa, wa), ka
+        s3 = mul(3, _ec_add(wa, wb))
+        assert got(o_w) == _ec_add(s3, _ec_add(wa, _ec_add(wb, wb))), (ka, kb)
