@@ -369,7 +369,7 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         // Small jobs are chains of dependent additions on a nearly empty chip: everything from here to the copy back
         // in ONE launch on the slot's own stream (msm_finalize.hip: k_small_msm), no bucket memset, no stream hand-over.
         if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 3], st));
-        launch_small_msm(st, ctx->d_table, s.d_sorted, s.d_offs, nbt, lanes, s.d_buckets, s.d_part_a, s.d_part_b,
+        launch_small_msm(st, ctx->d_table, s.d_sorted, s.d_offs, nbt, lanes, max_refs, s.d_buckets, s.d_part_a, s.d_part_b,
                          s.d_heavy_ws, s.d_small + 26, stage1, stage2, ctx->small_lds_bytes);
         if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], st));
     } else {

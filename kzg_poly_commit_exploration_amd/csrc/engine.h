@@ -100,8 +100,9 @@ struct TreeSumDesc;
 uint32_t small_msm_lds_bytes();
 const void* small_msm_kernel();
 void launch_small_msm(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs, uint32_t nb,
-                      uint32_t lanes, void* d_buckets, void* d_part_a, void* d_part_b, void* d_heavy_ws, uint32_t* d_refs_out,
-                      const TreeSumDesc* stage1 /* 2 */, const TreeSumDesc* stage2 /* 4 */, uint32_t lds_bytes);
+                      uint32_t lanes, uint64_t max_refs, void* d_buckets, void* d_part_a, void* d_part_b, void* d_heavy_ws,
+                      uint32_t* d_refs_out, const TreeSumDesc* stage1 /* 2 */, const TreeSumDesc* stage2 /* 4 */,
+                      uint32_t lds_bytes);
 // out[g] = sum_{q<len} in[g*gstride + q*estride], XYZZ records: log-depth tree per group;
 // up to four independent jobs per launch
 // group g reads in[(g / inner) * ostride + (g % inner) * gstride + q * estride], q < len

@@ -350,9 +350,11 @@ struct SmallJob {
     HeavyWs ws;
     TreeJob tj[6];                    // [0..1] stage 1 (Row, Col), [2..5] stage 2
     uint32_t nb, lanes, group;        // accumulation / finalisation geometry
+    uint32_t direct;                  // no phase A: the bucket groups of phase B add table points themselves
     uint32_t items_a, items_b, items_c, items_d;
 };
 
+constexpr uint32_t kDirectGroupRefs = 128;  // direct mode: references of one bucket a group of quads adds by itself
 constexpr uint32_t kSyncTicket = 32, kSyncDoneA = 64, kSyncDoneB = 96, kSyncDoneH = 128, kSyncDoneC = 160;  // words of the header
 __device__ __forceinline__ void spin_until(const uint32_t* p, uint32_t n) {
     // ~0.4 us between polls: up to 255 workgroups wait on one word that the working ones have to increment
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(64 * kCoop, 1) k_small_msm(SmallJob job) {
         const uint32_t phase = s_ticket & 7u, item = s_ticket >> 3;
         if (phase == 5) break;
         if (phase) __threadfence();  // acquire: results of the earlier phases are read below
-        if (phase == 2) {
+        if (phase == 2 && !job.direct) {
             heavy_item(item, job.part_a, job.part_b, job.buckets, job.ws, lds, &s_last);
         } else {
             // ---- set up this quad's part of the item ----
@@ -411,6 +413,8 @@ __global__ void __launch_bounds__(64 * kCoop, 1) k_small_msm(SmallJob job) {
             size_t p_stride = 0;
             uint32_t cnt = 0, gsz = 1, l = 0;
             uint4* out = nullptr;
+            // direct mode (phases B and H): the operands are table points, reference i of this quad at r_base[i * gsz]
+            const uint32_t* r_base = nullptr;
             if (phase == 0) {
                 if (item == 0 && threadIdx.x == 0 && job.refs_out) job.refs_out[0] = job.offs[job.nb];
                 lane = item * 64 + t;
@@ -427,6 +431,26 @@ __global__ void __launch_bounds__(64 * kCoop, 1) k_small_msm(SmallJob job) {
                     next = load_table_point(job.table, job.sorted[start]);
                 }
                 cnt = end - start;
+            } else if (job.direct && phase <= 2) {
+                // phase B: a group of quads per bucket; a bucket with more than kDirectGroupRefs references is left to a
+                // whole workgroup of phase H (listed in ws.owner1, counted in counters[1])
+                if (phase == 1 && item == 0 && threadIdx.x == 0 && job.refs_out) job.refs_out[0] = job.offs[job.nb];
+                gsz = phase == 1 ? job.group : 64u;
+                l = t & (gsz - 1);
+                const uint32_t bk = phase == 1 ? item * (64 / gsz) + t / gsz : job.ws.owner1[item];
+                if (bk < job.nb) {
+                    const uint32_t s = job.offs[bk], e = job.offs[bk + 1];
+                    if (s == e) {
+                        if (l == 0 && lead) store_xyzz30(job.buckets + (size_t)bk * kXyzzU4, xyzz30_inf());
+                    } else if (phase == 1 && e - s > kDirectGroupRefs) {
+                        if (l == 0 && lead) job.ws.owner1[atomicAdd(&job.ws.counters[1], 1u)] = bk;
+                    } else {
+                        cnt = e - s > l ? (e - s - l + gsz - 1) / gsz : 0;
+                        r_base = job.sorted + s + l;
+                        if (cnt) next = load_table_point(job.table, r_base[0]);
+                        if (l == 0) out = job.buckets + (size_t)bk * kXyzzU4;
+                    }
+                }
             } else if (phase == 1) {
                 gsz = job.group;
                 l = t & (gsz - 1);
@@ -484,7 +508,7 @@ __global__ void __launch_bounds__(64 * kCoop, 1) k_small_msm(SmallJob job) {
                     if (l == 0) out = J.out + (size_t)g * kXyzzU4;
                 }
             }
-            if (phase != 0 && cnt) next = load_xyzz30(p_first);
+            if (phase != 0 && !r_base && cnt) next = load_xyzz30(p_first);
             atomicMax(&s_max, cnt);
             __syncthreads();
             const uint32_t n_serial = s_max;
@@ -511,7 +535,8 @@ __global__ void __launch_bounds__(64 * kCoop, 1) k_small_msm(SmallJob job) {
                             }
                             if (step + 1 < cnt) next = load_table_point(job.table, job.sorted[e + 1]);
                         } else if (step + 1 < cnt) {
-                            next = load_xyzz30(p_base + (size_t)(step + 1) * p_stride);
+                            next = r_base ? load_table_point(job.table, r_base[(size_t)(step + 1) * gsz])
+                                          : load_xyzz30(p_base + (size_t)(step + 1) * p_stride);
                         }
                     }
                 } else {
@@ -583,8 +608,8 @@ uint32_t small_msm_lds_bytes() { return 84u * 1024u; }  // more than half a CU's
 const void* small_msm_kernel() { return (const void*)k_small_msm; }
 
 void launch_small_msm(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs, uint32_t nb,
-                      uint32_t lanes, void* d_buckets, void* d_part_a, void* d_part_b, void* d_heavy_ws, uint32_t* d_refs_out,
-                      const TreeSumDesc* stage1, const TreeSumDesc* stage2, uint32_t lds_bytes) {
+                      uint32_t lanes, uint64_t max_refs, void* d_buckets, void* d_part_a, void* d_part_b, void* d_heavy_ws,
+                      uint32_t* d_refs_out, const TreeSumDesc* stage1, const TreeSumDesc* stage2, uint32_t lds_bytes) {
     SmallJob job;
     job.table = reinterpret_cast<const uint4*>(d_table);
     job.sorted = d_sorted;
@@ -597,7 +622,10 @@ void launch_small_msm(hipStream_t s, const void* d_table, const uint32_t* d_sort
     job.nb = nb;
     job.lanes = lanes;
     job.group = finalize_group_size(nb);
-    job.items_a = (lanes + 63) / 64;
+    // Very small jobs (an average bucket holds at most 32 references: degree <= 127 at the 8-bit width) skip the
+    // accumulation phase: 2 serial additions + 4 tree levels per bucket instead of 3 + a phase boundary + 1 + 3.
+    job.direct = max_refs <= (uint64_t)nb * 32 ? 1u : 0u;
+    job.items_a = job.direct ? 0u : (lanes + 63) / 64;
     job.items_b = (nb + 64 / job.group - 1) / (64 / job.group);
     job.items_c = plan_tree_jobs(job.tj, stage1, 2, 0, 1);
     job.items_d = plan_tree_jobs(job.tj + 2, stage2, 4, job.items_c, 1);

@@ -749,7 +749,8 @@ def test_small_jobs_one_launch_and_general_path_agree(oracle, golden):
     phases of ONE launch (msm_finalize.hip: k_small_msm); KZG_SMALL_MSM=0 sends them through the general kernels
     instead (group finalisation, two-stage tree launch).  Both must give the oracle's commitment: ragged sizes around
     the workgroup and threshold boundaries, uniform and skewed coefficients (one bucket takes every point: the
-    long-bucket phase inside the launch), a degenerate secret (every SRS point equal: doublings in every tree)."""
+    long-bucket phase inside the launch; at 101 terms and below the direct form without an accumulation phase and its
+    whole-workgroup buckets), a degenerate secret (every SRS point equal: doublings in every tree)."""
     import subprocess
     import sys
 
@@ -772,6 +773,8 @@ for n in (1, 2, 3, 17, 64, 101, 257, 1001, 2501, 2521, 2731, 4096, 5000):
     out["ones_%%d" %% n] = eng.commit_limbs(K.scalars_to_limbs([1] * n)).compress().hex()
     out["neg_%%d" %% n] = eng.commit_limbs(K.scalars_to_limbs([r - 3] * n)).compress().hex()
     out["sparse_%%d" %% n] = eng.commit_limbs(K.scalars_to_limbs([(i %% 7 == 0) * (i + 1) for i in range(n)])).compress().hex()
+    same = sum(256 ** k for k in range(31))  # every 8-bit window holds the digit 1: ONE bucket takes all 31 n references
+    out["same_%%d" %% n] = eng.commit_limbs(K.scalars_to_limbs([same] * n)).compress().hex()
     eng.close()
 e2 = K.SetupArtifactsGenerator((1).to_bytes(32, "big")).take(1500)
 out["secret_one"] = e2.commit_limbs(K.scalars_to_limbs([(i * i + 3) %% r for i in range(1500)])).compress().hex()
@@ -787,13 +790,14 @@ print(json.dumps(out))
     assert res["1"] == res["0"]
     secret = bytes.fromhex(golden["secret_be"])
     r = K.R_MODULUS
-    for n in (1, 101, 2501, 2731, 5000):
+    for n in (1, 17, 101, 2501, 2731, 5000):
         vals, p5 = [], 1
         for _ in range(n):
             vals.append((p5 + 10) % r)
             p5 = p5 * 5 % r
         for name, coeffs in (("bench", vals), ("ones", [1] * n), ("neg", [r - 3] * n),
-                             ("sparse", [(i % 7 == 0) * (i + 1) for i in range(n)])):
+                             ("sparse", [(i % 7 == 0) * (i + 1) for i in range(n)]),
+                             ("same", [sum(256 ** k for k in range(31))] * n)):
             want = oracle.p1_compress(oracle.commit_shortcut(K.scalars_to_limbs(coeffs), secret))
             assert res["1"]["%s_%d" % (name, n)] == want.hex(), (name, n)
     want = oracle.p1_compress(oracle.commit_shortcut(K.scalars_to_limbs([(i * i + 3) % r for i in range(1500)]),
