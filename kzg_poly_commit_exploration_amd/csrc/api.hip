@@ -394,7 +394,7 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
                                finalize_group_size(nbt));
         // (gating the finalisation as well measured 3-5 % slower: it is short and wants to run at once)
         if (ctx->gate_lds_bytes && !alone) hipLaunchKernelGGL(k_reduce_gate, dim3(1), dim3(64), ctx->gate_lds_bytes, st, (uint32_t*)nullptr);
-        launch_tree_sums_two_stage(st, stage1, 2, stage2, 4, (uint32_t*)s.d_heavy_ws + 64);
+        launch_tree_sums_two_stage(st, stage1, 2, stage2, 4, (uint32_t*)s.d_heavy_ws + 64, alone);
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 5], st));
     HIP_TRY(ctx, hipMemcpyAsync(s.h_final, s.d_final, ctx->final_records * batch * kXyzzBytes, hipMemcpyDeviceToHost,

@@ -114,11 +114,11 @@ struct TreeSumDesc {
     uint32_t inner;    // groups per outer block (= groups when there is no batch dimension)
     uint64_t ostride;  // record stride between outer blocks
 };
-void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count, bool dense = false);
+void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count, bool dense = false, bool alone = true);
 // stage2 reads what stage1 wrote.  One launch when both stages fit the chip at once (d_sync: two zeroed words, e.g.
 // words 4 and 5 of d_heavy_ws), otherwise two launches.
 void launch_tree_sums_two_stage(hipStream_t s, const TreeSumDesc* stage1, uint32_t count1, const TreeSumDesc* stage2,
-                                uint32_t count2, uint32_t* d_sync);
+                                uint32_t count2, uint32_t* d_sync, bool alone);
 
 // ---- srs_kernels.hip --------------------------------------------------------------------
 // blst_p1 Jacobian (host layout, strided) already copied to d_jac (n x 144 B contiguous) -> affine

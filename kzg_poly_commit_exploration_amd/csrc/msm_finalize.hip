@@ -627,8 +627,8 @@ void launch_small_msm(hipStream_t s, const void* d_table, const uint32_t* d_sort
     job.direct = max_refs <= (uint64_t)nb * 32 ? 1u : 0u;
     job.items_a = job.direct ? 0u : (lanes + 63) / 64;
     job.items_b = (nb + 64 / job.group - 1) / (64 / job.group);
-    job.items_c = plan_tree_jobs(job.tj, stage1, 2, 0, 1);
-    job.items_d = plan_tree_jobs(job.tj + 2, stage2, 4, job.items_c, 1);
+    job.items_c = plan_tree_jobs(job.tj, stage1, 2, 0, 256u * kTreeLogical);
+    job.items_d = plan_tree_jobs(job.tj + 2, stage2, 4, job.items_c, 256u * kTreeLogical);
     const uint32_t items = job.items_a + job.items_b + job.items_c + job.items_d;
     hipLaunchKernelGGL(k_small_msm, dim3(items < 256 ? items : 256), dim3(64 * kCoop), lds_bytes, s, job);
 }

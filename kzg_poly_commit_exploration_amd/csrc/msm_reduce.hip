@@ -118,8 +118,9 @@ __global__ void __launch_bounds__(kTreeBlock, KZG_TREE_WAVES) k_tree_sum(TreeJob
     }
 }
 
-static uint32_t plan_jobs(TreeJobs& jobs, uint32_t first, const TreeSumDesc* descs, uint32_t count, uint32_t first_block) {
-    return plan_tree_jobs(jobs.j + first, descs, count, first_block, KZG_TREE_WAVES);
+static uint32_t plan_jobs(TreeJobs& jobs, uint32_t first, const TreeSumDesc* descs, uint32_t count, uint32_t first_block,
+                          bool alone = true) {
+    return plan_tree_jobs(jobs.j + first, descs, count, first_block, alone ? 256u * kTreeLogical : 64u * kTreeLogical);
 }
 
 static bool dense_trees(const TreeSumDesc* descs, uint32_t count) {
@@ -128,29 +129,29 @@ static bool dense_trees(const TreeSumDesc* descs, uint32_t count) {
     return total <= 2 * 16384;  // (stage 1 sums every bucket twice: rows and columns)
 }
 
-void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count, bool dense) {
+void launch_tree_sums(hipStream_t s, const TreeSumDesc* descs, uint32_t count, bool dense, bool alone) {
     if (count > 6) count = 6;
     TreeJobs jobs;
     jobs.count = count;
     jobs.stage1_blocks = 0;
     jobs.sync = nullptr;
-    const uint32_t blocks = plan_jobs(jobs, 0, descs, count, 0);
+    const uint32_t blocks = plan_jobs(jobs, 0, descs, count, 0, alone);
     if (!blocks) return;
     if (dense) hipLaunchKernelGGL(k_tree_sum<true>, dim3(blocks), dim3(kTreeBlock), 0, s, jobs);
     else hipLaunchKernelGGL(k_tree_sum<false>, dim3(blocks), dim3(kTreeBlock), 0, s, jobs);
 }
 
 void launch_tree_sums_two_stage(hipStream_t s, const TreeSumDesc* stage1, uint32_t count1, const TreeSumDesc* stage2,
-                                uint32_t count2, uint32_t* d_sync) {
+                                uint32_t count2, uint32_t* d_sync, bool alone) {
     TreeJobs jobs;
     jobs.count = count1 + count2;
-    const uint32_t b1 = count1 + count2 <= 6 ? plan_jobs(jobs, 0, stage1, count1, 0) : 0;
-    const uint32_t b2 = b1 ? plan_jobs(jobs, count1, stage2, count2, b1) : 0;
+    const uint32_t b1 = count1 + count2 <= 6 ? plan_jobs(jobs, 0, stage1, count1, 0, alone) : 0;
+    const uint32_t b2 = b1 ? plan_jobs(jobs, count1, stage2, count2, b1, alone) : 0;
     // one launch only while every workgroup is resident at once anyway (two per CU); else two launches
-    const bool dense = dense_trees(stage1, count1);
+    const bool dense = alone || dense_trees(stage1, count1);  // (a lone job has no neighbour whose accumulation the dense form could slow)
     if (!d_sync || !b1 || !b2 || b1 + b2 > 512) {
-        launch_tree_sums(s, stage1, count1, dense);
-        launch_tree_sums(s, stage2, count2, dense);
+        launch_tree_sums(s, stage1, count1, dense, alone);
+        launch_tree_sums(s, stage2, count2, dense, alone);
         return;
     }
     jobs.stage1_blocks = b1;

@@ -20,28 +20,44 @@ struct TreeJob {
 };
 
 // fills j[0 .. count) and returns the number of workgroups they take; first_block = number of the first one
-inline uint32_t plan_tree_jobs(TreeJob* j, const TreeSumDesc* descs, uint32_t count, uint32_t first_block, uint32_t waves_per_simd) {
+inline uint32_t plan_tree_jobs(TreeJob* j, const TreeSumDesc* descs, uint32_t count, uint32_t first_block, uint32_t resident_quads) {
     // One (logical) lane per element gives the shortest chain (log2(len) dependent additions) but only ~1/log2(len)
-    // of the lane-steps do work.  A CU holds one workgroup (one wave per SIMD) = 64 logical lanes: beyond 256
-    // workgroups a second round would start, which costs a whole tree's latency -- lanes then pre-add several
-    // elements serially instead (one more dependent addition per doubling).
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < count; i++) total += (uint64_t)descs[i].groups * descs[i].len;
-    const uint64_t resident_lanes = (uint64_t)waves_per_simd * 256 * kTreeLogical;
-    uint32_t per_lane = 1;
-    while ((total + per_lane - 1) / per_lane > resident_lanes && per_lane < 64) per_lane <<= 1;
+    // of the lane-steps do work, and a group cannot be wider than one workgroup (64 quads).  A CU holds one workgroup
+    // (one wave per SIMD): beyond 256 workgroups a second round would start, which costs a whole tree's latency, so
+    // the groups are narrowed until the launch fits one round -- lanes then pre-add several elements serially (one more
+    // dependent addition per halving).  (Round 2 fix: the first version divided the already capped width once more and
+    // gave the 256-element sums of a 2^20-term job 8 quads of 32 serial additions each, on a quarter of the chip:
+    // 285 us for the two stages.)  resident_quads: 256 x 64 for a job that has the chip to itself; a quarter of that when
+    // other slots are busy -- the trees then run beside an accumulation kernel that leaves them one wave slot per SIMD at
+    // best, and four times the waves for 0.4 x the time cost it 1.5 % (measured, pipelined 2^20).
+    uint32_t lpg[8];
+    if (count > 8) count = 8;
+    uint64_t quads = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        lpg[i] = 1;
+        while (lpg[i] < descs[i].len && lpg[i] < kTreeLogical) lpg[i] <<= 1;
+        quads += (uint64_t)descs[i].groups * lpg[i];
+    }
+    const uint64_t resident_lanes = resident_quads;
+    while (quads > resident_lanes) {
+        uint32_t widest = 1;
+        for (uint32_t i = 0; i < count; i++) widest = lpg[i] > widest ? lpg[i] : widest;
+        if (widest == 1) break;
+        quads = 0;
+        for (uint32_t i = 0; i < count; i++) {
+            if (lpg[i] == widest) lpg[i] >>= 1;
+            quads += (uint64_t)descs[i].groups * lpg[i];
+        }
+    }
     uint32_t blocks = first_block;
     for (uint32_t i = 0; i < count; i++) {
-        uint32_t lpg = 1;
-        while (lpg < descs[i].len && lpg < kTreeLogical) lpg <<= 1;
-        lpg = lpg / per_lane ? lpg / per_lane : 1;
-        const uint32_t gpb = kTreeLogical / lpg;
+        const uint32_t gpb = kTreeLogical / lpg[i];
         TreeJob& J = j[i];
         J.in = reinterpret_cast<const uint4*>(descs[i].in);
         J.out = reinterpret_cast<uint4*>(descs[i].out);
         J.groups = descs[i].groups;
         J.len = descs[i].len;
-        J.lanes_per_group = lpg;
+        J.lanes_per_group = lpg[i];
         J.first_block = blocks;
         J.gstride = descs[i].gstride;
         J.estride = descs[i].estride;
