@@ -560,8 +560,40 @@ __global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ 
         if (base + t < nb) d_offs[base + t] += add;
 }
 
+// The same scan in ONE workgroup and one launch, for tables of up to kScanSingleMax entries: lane t sums its run of
+// consecutive entries, the 1024 partial sums are scanned in LDS, the run is rewritten.  A launch costs ~5 us whatever it
+// does; the three launches above are 15 us, one such kernel 4.5 us on a small table.
+constexpr uint32_t kScanSingleMax = 8192;  // (65536 entries in one workgroup took 32 us: strided runs of 64 per lane)
+__global__ void __launch_bounds__(1024) k_scan_single(uint32_t* __restrict__ d_buf, uint32_t count, uint32_t* __restrict__ d_total_out) {
+    __shared__ u32 lds[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (count + 1023u) / 1024u;
+    const uint32_t lo = t * per < count ? t * per : count, hi = lo + per < count ? lo + per : count;
+    u32 sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += d_buf[i];
+    lds[t] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+        const u32 add = t >= off ? lds[t - off] : 0u;
+        __syncthreads();
+        lds[t] += add;
+        __syncthreads();
+    }
+    u32 run = lds[t] - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        const u32 v = d_buf[i];
+        d_buf[i] = run;
+        run += v;
+    }
+    if (t == 1023) *d_total_out = lds[1023];
+}
+
 // exclusive scan of `count` u32 (count <= 2^20) in place: d_buf -> offsets, total -> *d_total
 static void scan_inplace(hipStream_t s, uint32_t* d_buf, uint32_t count, uint32_t* d_block_sums, uint32_t* d_total) {
+    if (count <= kScanSingleMax) {
+        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, s, d_buf, count, d_total);
+        return;
+    }
     uint32_t nblocks = (count + kScanTile - 1) / kScanTile;
     hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(kScanBlock), 0, s, d_buf, count, d_buf, d_block_sums);
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, d_block_sums, nblocks, d_total);
