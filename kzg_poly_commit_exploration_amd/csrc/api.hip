@@ -373,7 +373,6 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
                          s.d_heavy_ws, s.d_small + 26, stage1, stage2, ctx->small_lds_bytes);
         if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], st));
     } else {
-        HIP_TRY(ctx, hipMemsetAsync(s.d_buckets, 0, (size_t)nbt * kXyzzBytes, st));  // zero = infinity
         // hand over to the shared accumulation stream and back (each hand-over costs ~12 us: not when no other slot
         // has work whose accumulation this one could collide with)
         const bool hand_over = ctx->serialize_accum && !alone;

@@ -66,7 +66,7 @@ uint32_t sort_count_entries(uint32_t max_batch, MsmConfig cfg);
 uint32_t sort_max_batch(MsmConfig cfg);
 uint32_t sort_workspace_words();
 // d_header: kHeavyHeaderBytes that the job wants zeroed before its next kernel; returns true when the sort did that
-// itself (the one-kernel sort of small jobs), false when the caller has to memset them.
+// itself (it does whenever it launches anything), false when the caller has to memset them (n == 0).
 bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n, uint32_t batch,
                         uint64_t stride, uint32_t table_stride, MsmConfig cfg, uint32_t* d_cnt,
                         uint32_t* d_ws, uint64_t* d_pairs, uint32_t* d_offs, uint32_t* d_sorted, uint32_t* d_header);

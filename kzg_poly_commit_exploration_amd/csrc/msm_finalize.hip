@@ -90,7 +90,10 @@ __global__ void __launch_bounds__(64 * kCoop, KZG_TREE_WAVES) k_bucket_finalize(
     if (b >= nb) return;
     const uint32_t L = accumulate_seg_len(offs[nb], lanes);
     uint32_t s = offs[b], e = offs[b + 1];
-    if (s == e) return;  // empty bucket: stays at infinity (buffer pre-zeroed)
+    if (s == e) {  // empty bucket: written as infinity here (the bucket array is not cleared between jobs)
+        if (lead) store_xyzz30(buckets + (size_t)b * kXyzzU4, xyzz30_inf());
+        return;
+    }
     uint32_t l_lo = s / L, l_hi = (e - 1) / L;
     if (l_lo == l_hi) return;  // inside one segment: written complete by k_bucket_accumulate
     const uint32_t span = l_hi - l_lo + 1;
@@ -169,7 +172,9 @@ __global__ void __launch_bounds__(64 * kCoop, KZG_TREE_WAVES) k_bucket_finalize_
     if (b < nb) {
         const uint32_t L = accumulate_seg_len(offs[nb], lanes);
         const uint32_t s = offs[b], e = offs[b + 1];
-        if (s != e) {  // (empty buckets stay at infinity: the array was zeroed)
+        if (s == e) {  // empty bucket: written as infinity here (the bucket array is not cleared between jobs)
+            if (l == 0 && lead) store_xyzz30(buckets + (size_t)b * kXyzzU4, xyzz30_inf());
+        } else {
             l_lo = s / L;
             const uint32_t l_hi = (e - 1) / L;
             if (l_lo != l_hi) {  // (inside one segment: written complete by the accumulation kernel)

@@ -316,9 +316,11 @@ KZG_DEV uint32_t bin_start(const uint32_t* __restrict__ d_cnt_scanned, uint32_t 
 
 __global__ void __launch_bounds__(1024) k_fine_plan(const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
                                                     uint32_t coarse_bins, const uint32_t* __restrict__ d_total,
-                                                    uint32_t ch, uint32_t* __restrict__ d_prefix) {
+                                                    uint32_t ch, uint32_t* __restrict__ d_prefix,
+                                                    uint32_t* __restrict__ d_header) {
     __shared__ u32 lds[1024];
     const int t = threadIdx.x;
+    if ((uint32_t)t < kHeavyHeaderBytes / 4) d_header[t] = 0;  // the job's counters (one stream operation fewer per job)
     const uint32_t total = *d_total;
     u32 v[2];
 #pragma unroll
@@ -696,7 +698,7 @@ bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, u
     const uint32_t ch = fine_chunk_len(max_pairs);
     const uint32_t max_chunks = (uint32_t)((max_pairs + ch - 1) / ch) + g.coarse_bins;  // <= kFineMaxChunks
     const uint32_t fine = 1u << g.fine_bits;
-    hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(1024), 0, s, d_cnt, g.tiles, g.coarse_bins, d_total, ch, d_prefix);
+    hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(1024), 0, s, d_cnt, g.tiles, g.coarse_bins, d_total, ch, d_prefix, d_header);
     hipLaunchKernelGGL(k_fine_count, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
                        g.coarse_bins, d_total, ch, d_prefix, d_table);
     // entries past the last chunk are stale; an exclusive scan never lets them reach the valid prefix
@@ -705,7 +707,7 @@ bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, u
                        g.coarse_bins, nb_total, d_total, d_prefix, d_table, d_offs);
     hipLaunchKernelGGL(k_fine_scatter, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
                        g.coarse_bins, d_total, ch, d_prefix, d_table, d_sorted);
-    return false;
+    return true;
 }
 
 }  // namespace kzg
