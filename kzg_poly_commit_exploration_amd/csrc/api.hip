@@ -3,8 +3,8 @@
 // tail (a few dozen point additions + one inversion) that finishes each MSM on the host.
 //
 // One commitment on a slot's stream:
-//   memset(hist) -> digits+histogram -> scan -> scatter -> bucket accumulation
-//   -> bucket finalisation -> row / column tree sums of the bucket matrix, split once more
+//   digits+histogram -> scan -> scatter -> bucket accumulation -> bucket finalisation
+//   -> row / column tree sums of the bucket matrix, split once more (small jobs: one launch behind the sort)
 //   -> D2H of <= 128 XYZZ partials -> host: four short weighted sums, normalise, blst_p1 out.
 // Nothing here falls back to the CPU for the MSM or the division: without a device the context
 // cannot be created.

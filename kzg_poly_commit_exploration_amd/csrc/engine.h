@@ -79,13 +79,14 @@ uint32_t accumulate_lanes(uint64_t max_refs, bool alone = false);
 // shared inversions), or null to run plain mixed additions; max_refs bounds the references of this launch
 size_t accumulate_pair_scratch_bytes(uint64_t max_refs);
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
-                              uint32_t nb, uint32_t lanes, void* d_buckets /* pre-zeroed */,
+                              uint32_t nb, uint32_t lanes, void* d_buckets /* complete buckets only: the rest by the finalisation */,
                               void* d_part_a, void* d_part_b, uint32_t lds_reserve_bytes, void* d_pair_scratch,
                               uint64_t max_refs);
 // adds the head / tail partials of buckets that span several segments (serial for short runs, three passes of
-// 64-wide trees for long ones); d_heavy_ws: heavy_workspace_bytes() of scratch whose first kHeavyHeaderBytes (the
-// counters) the caller has zeroed -- ahead of time, so that nothing sits between the end of the accumulation
-// and this launch (a fill kernel there lets the next slot's accumulation take the chip first: +0.9 ms)
+// 64-wide trees for long ones) and writes empty buckets as infinity: every bucket is written once per job, the array is
+// never cleared.  d_heavy_ws: heavy_workspace_bytes() of scratch whose first kHeavyHeaderBytes (the counters) are zero
+// (launch_bucket_sort does that) -- ahead of time, so that nothing sits between the end of the accumulation and this
+// launch (a fill kernel there lets the next slot's accumulation take the chip first: +0.9 ms)
 size_t heavy_workspace_bytes();
 // group: quads per bucket (finalize_group_size(nb); 1 = one quad per bucket, the throughput form).
 void launch_bucket_finalize(hipStream_t s, const uint32_t* d_offs, uint32_t nb, uint32_t lanes, const void* d_part_a,
