@@ -26,7 +26,9 @@
 
 namespace kzg {
 
-constexpr int kPolyL = 16;        // coefficients per lane (2^20 coefficients: 4 -> 134 us, 8 -> 109, 16 -> 100 for the three kernels)
+constexpr int kPolyL = 8;        // coefficients per lane.  Alone at 2^20: 4 -> 134 us, 8 -> 109, 16 -> 100 for the three kernels, but
+                                 // with 16 the pipelined opening proofs drop 5 % (374-379 against 392-398 per s: half as many, longer
+                                 // waves wait longer for room beside the other slots' accumulation), so 8 stays
 constexpr int kPolyBlock = 256;  // lanes per workgroup
 constexpr int kPolyTile = kPolyL * kPolyBlock;
 
