@@ -14,9 +14,12 @@
  *
  * Conventions: plain pointers and sizes only; the caller owns every buffer; the library copies what
  * it keeps and never retains a host pointer past return; every function returns 0 (KZG_OK) or a
- * negative kzg_status; nothing throws or longjmps across the boundary.  One kzg_ctx drives one GPU
- * (one process per GPU; see bench.py for the RCCL exchange); calls on one context are serialised
- * internally, different contexts are independent.
+ * negative kzg_status; nothing throws or longjmps across the boundary.  A kzg_ctx drives one GPU
+ * (kzg_ctx_create; one process per GPU with the RCCL exchange in the host program, see bench.py) or several GPUs of
+ * one node from one process (kzg_ctx_create_multi / _ex: SRS split by point range with an RCCL exchange of the partial
+ * sums inside the library, or SRS replicated with batches split by polynomial).  Every entry point may be called
+ * from several threads on the same context: the synchronous host-pointer calls (kzg_commit, kzg_open, kzg_*_batch)
+ * each take one of the context's stream slots and run side by side; different contexts are independent.
  *
  * There is no CPU fallback: without a HIP device kzg_ctx_create fails with KZG_ERR_NO_DEVICE.
  */
@@ -31,6 +34,12 @@ extern "C" {
 #endif
 
 typedef struct kzg_ctx kzg_ctx;
+
+/* Bumped whenever a struct or a signature below changes incompatibly (2: kzg_kernel_times lost `scan_ms` in round 2;
+ * 3: kzg_ctx_create_multi_ex, host-pointer batches).  kzg_abi_version() returns the value the library was built
+ * with: a caller compiled against another value must not read kzg_kernel_times. */
+#define KZG_ABI_VERSION 3
+int kzg_abi_version(void);
 
 typedef enum kzg_status {
     KZG_OK = 0,
@@ -64,10 +73,20 @@ int kzg_ctx_create(int device, kzg_ctx** out);
  * exchanged with ncclAllGather (librccl, one communicator per device, single process) and added with kzg_g1_sum:
  * RCCL has no reduction operator for curve points, so "reduce" = all-gather + K-1 complete additions.
  * A device may be listed more than once (virtual slices: how a one-GPU box rehearses the path); such a context
- * gathers on the host, since a communicator needs distinct devices.  ndev == 1 behaves like kzg_ctx_create.
- * kzg_evaluate / kzg_quotient run on devices[0].  The asynchronous and device-pointer entry points (submit / wait /
- * batch / kzg_dev_*) belong to one device and return KZG_ERR_INVALID_ARG on a multi-device context. */
+ * gathers on the host, since a communicator needs distinct devices (the same fallback is taken when RCCL cannot
+ * form the communicator).  kzg_evaluate / kzg_quotient run on devices[0].  The host-pointer batches
+ * (kzg_commit_batch / kzg_open_batch) work on every kind of context.  The asynchronous and device-pointer entry points
+ * (kzg_*_submit / kzg_wait* / kzg_dev_*) name ONE device's memory and slots: they return KZG_ERR_INVALID_ARG on a
+ * multi-device context, also when ndev == 1.
+ *
+ * kzg_ctx_create_multi_ex(..., KZG_MULTI_REPLICATE_SRS, ...): every device keeps the WHOLE SRS and work is split by
+ * polynomial instead (BASELINE config 5: 64 openings of degree 2^20 on 8 GPUs): polynomial p
+ * of a kzg_commit_batch / kzg_open_batch goes to devices[p mod ndev], each device pipelines its share through its
+ * stream slots, nothing is exchanged.  Single kzg_commit / kzg_open calls take the devices in turn, so caller
+ * threads spread over the GPUs.  flags == 0 is kzg_ctx_create_multi. */
+#define KZG_MULTI_REPLICATE_SRS 1u
 int kzg_ctx_create_multi(const int* devices, int ndev, kzg_ctx** out);
+int kzg_ctx_create_multi_ex(const int* devices, int ndev, unsigned flags, kzg_ctx** out);
 /* devices of the context (1 for kzg_ctx_create) and how many partial-sum exchanges went through RCCL so far */
 int kzg_num_devices(const kzg_ctx* ctx);
 uint64_t kzg_rccl_exchanges(const kzg_ctx* ctx);
@@ -133,6 +152,20 @@ int kzg_commit_le_bytes(kzg_ctx* ctx, const uint8_t* scalars_le, size_t n, uint6
  *   KZG_ERR_DEGREE_TOO_HIGH. */
 int kzg_open(kzg_ctx* ctx, const uint64_t* coeffs_fr_mont, size_t n, const uint64_t z[4],
              const uint64_t y[4], uint64_t out_p1[18]);
+
+/* `batch` calls of Polynomial::commit / Evaluation::generate_proof against the same SRS in one call, HOST pointers:
+ * polynomial p = n blst_fr values at coeffs + p * stride_coeffs * 4 (stride_coeffs >= n), result p at out_p1s + 18 * p.
+ * This is the loop of the reference's callers (src/lib.rs:16-33 per polynomial; benches/evaluation_proof.rs:51-54)
+ * handed over whole, so that uploads overlap kernels and, on a multi-device context, the polynomials spread over
+ * the GPUs (replicated SRS: by polynomial, no communication; range-split SRS: every polynomial sharded, one
+ * exchange per batch).  n <= kzg_srs_len (commit) / n - 1 <= kzg_srs_len (open): batches take truncated polynomials.
+ * kzg_open_batch opens polynomial p at zs[p] with claimed value ys[p] and fills statuses[p] with KZG_OK,
+ * KZG_ERR_CONSTANT_POLY or KZG_ERR_REMAINDER (out_p1s[p] is written only for KZG_OK); its return value reports
+ * failures of the call as a whole.  kzg_set_max_batch bounds the polynomials per pass of the kernels (default 1). */
+int kzg_commit_batch(kzg_ctx* ctx, const uint64_t* coeffs_fr_mont, size_t n, size_t batch, size_t stride_coeffs,
+                     uint64_t* out_p1s /* batch x 18 */);
+int kzg_open_batch(kzg_ctx* ctx, const uint64_t* coeffs_fr_mont, size_t n, size_t batch, size_t stride_coeffs,
+                   const uint64_t* zs, const uint64_t* ys, uint64_t* out_p1s /* batch x 18 */, int* statuses);
 
 /* Polynomial::sub + divide_by_root alone (reference src/polynomial.rs:128-195): writes the
  * quotient coefficients (Montgomery) to out_q (room for n-1 entries) and their count, after the

@@ -34,6 +34,8 @@ KZG_ERR_NO_DEVICE = -5
 KZG_ERR_HIP = -6
 KZG_ERR_NO_SRS = -7
 KZG_ERR_BUSY = -8
+KZG_MULTI_REPLICATE_SRS = 1
+KZG_ABI_VERSION = 3
 
 # every symbol include/kzg_mi355x.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -41,7 +43,7 @@ ABI_SYMBOLS = [
     "kzg_srs_load_g1", "kzg_srs_generate_g1", "kzg_srs_read_g1", "kzg_srs_len",
     "kzg_commit", "kzg_commit_le_bytes", "kzg_open", "kzg_quotient", "kzg_evaluate",
     "kzg_srs_load_affine", "kzg_srs_load_compressed", "kzg_srs_save", "kzg_srs_load_file",
-    "kzg_ctx_create_multi", "kzg_num_devices", "kzg_rccl_exchanges", "kzg_num_slots", "kzg_commit_submit", "kzg_open_submit", "kzg_wait",
+    "kzg_ctx_create_multi", "kzg_ctx_create_multi_ex", "kzg_abi_version", "kzg_commit_batch", "kzg_open_batch", "kzg_num_devices", "kzg_rccl_exchanges", "kzg_num_slots", "kzg_commit_submit", "kzg_open_submit", "kzg_wait",
     "kzg_set_max_batch", "kzg_max_batch", "kzg_commit_batch_submit", "kzg_wait_batch",
     "kzg_open_batch_submit", "kzg_wait_open_batch", "kzg_g1_uncompress",
     "kzg_dev_alloc", "kzg_dev_free", "kzg_dev_upload", "kzg_dev_download",
@@ -86,6 +88,10 @@ def load_library():
     sig = {
         "kzg_ctx_create": (i, [i, C.POINTER(vp)]),
         "kzg_ctx_create_multi": (i, [vp, i, C.POINTER(vp)]),
+        "kzg_ctx_create_multi_ex": (i, [vp, i, C.c_uint, C.POINTER(vp)]),
+        "kzg_abi_version": (i, []),
+        "kzg_commit_batch": (i, [vp, vp, sz, sz, sz, vp]),
+        "kzg_open_batch": (i, [vp, vp, sz, sz, sz, vp, vp, vp, vp]),
         "kzg_num_devices": (i, [vp]),
         "kzg_rccl_exchanges": (C.c_uint64, [vp]),
         "kzg_ctx_destroy": (None, [vp]),
@@ -289,14 +295,19 @@ def _check(rc, ctx=None):
 # Engine: one context = one GPU with a resident SRS (no reference analogue; see kzg_mi355x.h).
 # ---------------------------------------------------------------------------------------------
 class Engine:
-    def __init__(self, device=0, devices=None):
+    def __init__(self, device=0, devices=None, replicate=False):
         """device: one HIP device.  devices=[d0, d1, ...]: one context over several devices (kzg_ctx_create_multi):
-        the SRS is split by point range and commit / open shard transparently; a device may repeat (virtual slices)."""
+        the SRS is split by point range and commit / open shard transparently; a device may repeat (virtual slices).
+        replicate=True (kzg_ctx_create_multi_ex, KZG_MULTI_REPLICATE_SRS): every device keeps the whole SRS and
+        batches are split by polynomial, with nothing to exchange."""
         self._lib = load_library()
         h = C.c_void_p()
         if devices is not None:
             arr = (C.c_int * len(devices))(*[int(d) for d in devices])
-            _check(self._lib.kzg_ctx_create_multi(arr, len(devices), C.byref(h)))
+            if replicate:
+                _check(self._lib.kzg_ctx_create_multi_ex(arr, len(devices), KZG_MULTI_REPLICATE_SRS, C.byref(h)))
+            else:
+                _check(self._lib.kzg_ctx_create_multi(arr, len(devices), C.byref(h)))
             device = int(devices[0])
         else:
             _check(self._lib.kzg_ctx_create(int(device), C.byref(h)))
@@ -470,6 +481,36 @@ class Engine:
             else:
                 res.append(KzgError(int(st[i]), self._lib.kzg_strerror(int(st[i])).decode()))
         return res
+
+    # -- host-pointer batches (every kind of context) --
+    @staticmethod
+    def _stack(polys):
+        """list of (n, 4) arrays, or one (batch, n, 4) array -> contiguous (batch, n, 4) uint64"""
+        a = np.asarray(polys, dtype=np.uint64) if not isinstance(polys, np.ndarray) else polys
+        if a.ndim != 3:
+            a = np.stack([np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in polys])
+        return np.ascontiguousarray(a, dtype=np.uint64)
+
+    def commit_batch_host(self, polys):
+        """kzg_commit_batch: one call for a list of equally long polynomials in host memory."""
+        flat = self._stack(polys)
+        b, n = flat.shape[0], flat.shape[1]
+        out = np.zeros((b, 18), dtype=np.uint64)
+        _check(self._lib.kzg_commit_batch(self._h, _ptr(flat), n, b, n, _ptr(out)), self._h)
+        return [G1Point(out[i]) for i in range(b)]
+
+    def open_batch_host(self, polys, zs, ys):
+        """kzg_open_batch: returns a list of G1Point or KzgError per polynomial."""
+        flat = self._stack(polys)
+        b, n = flat.shape[0], flat.shape[1]
+        assert len(zs) == b and len(ys) == b
+        zl = np.ascontiguousarray(np.stack([z.limbs() for z in zs]))
+        yl = np.ascontiguousarray(np.stack([y.limbs() for y in ys]))
+        out = np.zeros((b, 18), dtype=np.uint64)
+        st = np.zeros(b, dtype=np.int32)
+        _check(self._lib.kzg_open_batch(self._h, _ptr(flat), n, b, n, _ptr(zl), _ptr(yl), _ptr(out), _ptr(st)), self._h)
+        return [G1Point(out[i]) if st[i] == KZG_OK else KzgError(int(st[i]), self._lib.kzg_strerror(int(st[i])).decode())
+                for i in range(b)]
 
     def commit_batch_limbs(self, polys):
         """Commits several coefficient arrays (each (n, 4) uint64, same n) in one batched pass."""

@@ -10,10 +10,15 @@
 // cannot be created.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -45,7 +50,9 @@ struct ReducePlan {
 
 // what a slot holds decides which wait entry point may collect it (a batched job's final buffer is laid out
 // [section][polynomial][record]; reading it as a single job would return a wrong point with KZG_OK)
-enum SlotKind { SLOT_IDLE = 0, SLOT_COMMIT = 1, SLOT_OPEN = 2, SLOT_TRIVIAL = 3, SLOT_COMMIT_BATCH = 4, SLOT_OPEN_BATCH = 5 };
+// SLOT_RESERVED: owned by a synchronous host-pointer call between its steps (upload -> submit -> wait), during which the
+// context mutex is NOT held: N caller threads occupy N slots and their jobs pipeline like explicit submits do.
+enum SlotKind { SLOT_IDLE = 0, SLOT_COMMIT = 1, SLOT_OPEN = 2, SLOT_TRIVIAL = 3, SLOT_COMMIT_BATCH = 4, SLOT_OPEN_BATCH = 5, SLOT_RESERVED = 6 };
 
 struct Slot {
     hipStream_t stream = nullptr;
@@ -96,6 +103,13 @@ struct kzg_ctx {
     kzg::MultiState* multi = nullptr;
     int device = 0;
     std::mutex mu;
+    std::condition_variable slot_cv;  // a slot became idle / a synchronous call finished
+    int sync_owned = 0;               // slots currently owned by synchronous host-pointer calls (reserve_slot)
+    bool raw_partials = false;        // kid of a range-split multi-device context: results stay un-normalised (ctx_set_raw_partials)
+    // KZG_HOST_TRACE=1: where a synchronous host-pointer call spends its wall time (printed when the context is destroyed)
+    bool host_trace = false;
+    std::atomic<uint64_t> trace_ns[5] = {};  // reserve (waiting for a slot), upload, submit, device wait, collect (host tail)
+    std::atomic<uint64_t> trace_calls{0};
     std::string last_error;
     // SRS
     size_t n = 0;  // points
@@ -431,10 +445,46 @@ hf::P1 finish_msm(const kzg_ctx* ctx, const Slot& s, uint32_t p = 0, uint32_t ba
     if (ctx->cfg.recode == kRecodeNaf) total = hf::px_double(total);
     const uint64_t* r2 = at(P.off_r2row, rh);
     for (uint32_t k = 0; k < rh; k++) total = hf::px_add(total, hf::px_from_record(r2 + (size_t)k * kXyzzWords64));
-    return hf::px_normalize(total);
+    // a kid of a range-split multi-device context hands its partial sum on as it is (Jacobian, two products); the
+    // parent pays the one inversion after adding the K partials (multi.hip)
+    return ctx->raw_partials ? hf::px_to_jacobian(total) : hf::px_normalize(total);
 }
 
 void write_p1(uint64_t out[18], const hf::P1& p) { std::memcpy(out, &p, sizeof p); }
+
+// ---- slot ownership of the synchronous host-pointer entry points (all of these with ctx->mu held) ------------------
+void slot_idle(kzg_ctx* ctx, Slot& s) {
+    s.kind = SLOT_IDLE;
+    ctx->slot_cv.notify_all();
+}
+// an idle slot, marked SLOT_RESERVED for the caller; -1 when none is free and (block == false, or every busy slot
+// belongs to an explicit submit whose owner may be this very thread: waiting for it could never end -> KZG_ERR_BUSY)
+int reserve_slot(kzg_ctx* ctx, std::unique_lock<std::mutex>& lk, bool block) {
+    for (;;) {
+        for (int i = 0; i < kNumSlots; i++)
+            if (ctx->slots[i].kind == SLOT_IDLE) {
+                ctx->slots[i].kind = SLOT_RESERVED;
+                ctx->sync_owned++;
+                return i;
+            }
+        if (!block || ctx->sync_owned == 0) return -1;
+        ctx->slot_cv.wait(lk);
+    }
+}
+void release_owned(kzg_ctx* ctx, int slot) {
+    if (ctx->slots[slot].kind == SLOT_RESERVED) ctx->slots[slot].kind = SLOT_IDLE;
+    ctx->sync_owned--;
+    ctx->slot_cv.notify_all();
+}
+struct SlotLease {  // declared after the lock it lives under: released first
+    kzg_ctx* ctx;
+    int slot;
+    ~SlotLease() { if (slot >= 0) release_owned(ctx, slot); }
+};
+// SRS replacement and workspace resizing wait until no synchronous call is between its steps
+void quiesce(kzg_ctx* ctx, std::unique_lock<std::mutex>& lk) {
+    while (ctx->sync_owned > 0) ctx->slot_cv.wait(lk);
+}
 
 bool host_tail_nonzero(const uint64_t* coeffs, size_t from, size_t n) {
     for (size_t i = from; i < n; i++)
@@ -511,13 +561,13 @@ const char* kzg_last_error(const kzg_ctx* ctx) {
     return ctx->last_error.c_str();
 }
 
-int kzg_ctx_create_multi(const int* devices, int ndev, kzg_ctx** out) {
+int kzg_ctx_create_multi_ex(const int* devices, int ndev, unsigned flags, kzg_ctx** out) {
     if (!out) return KZG_ERR_INVALID_ARG;
     *out = nullptr;
-    if (!devices || ndev <= 0) return KZG_ERR_INVALID_ARG;
+    if (!devices || ndev <= 0 || (flags & ~(unsigned)KZG_MULTI_REPLICATE_SRS)) return KZG_ERR_INVALID_ARG;
     kzg::MultiState* m = nullptr;
     std::string err;
-    int rc = multi_create(devices, ndev, &m, err);
+    int rc = multi_create(devices, ndev, (flags & KZG_MULTI_REPLICATE_SRS) ? kMultiReplicate : kMultiRange, &m, err);
     if (rc != KZG_OK) return rc;
     kzg_ctx* ctx = new kzg_ctx();
     ctx->multi = m;
@@ -525,6 +575,8 @@ int kzg_ctx_create_multi(const int* devices, int ndev, kzg_ctx** out) {
     *out = ctx;
     return KZG_OK;
 }
+int kzg_ctx_create_multi(const int* devices, int ndev, kzg_ctx** out) { return kzg_ctx_create_multi_ex(devices, ndev, 0u, out); }
+int kzg_abi_version(void) { return KZG_ABI_VERSION; }
 int kzg_num_devices(const kzg_ctx* ctx) { return !ctx ? 0 : (ctx->multi ? multi_num_devices(ctx->multi) : 1); }
 uint64_t kzg_rccl_exchanges(const kzg_ctx* ctx) { return (ctx && ctx->multi) ? multi_rccl_exchanges(ctx->multi) : 0; }
 
@@ -541,6 +593,7 @@ int kzg_ctx_create(int device, kzg_ctx** out) {
     if (const char* v = std::getenv("KZG_ACCUM_LDS_KB")) ctx->accum_lds_bytes = (uint32_t)std::atoi(v) * 1024u;
     if (const char* v = std::getenv("KZG_REDUCE_GATE_KB")) ctx->gate_lds_bytes = (uint32_t)std::atoi(v) * 1024u;
     if (const char* v = std::getenv("KZG_SMALL_MSM")) ctx->small_msm_off = std::atoi(v) == 0;
+    if (const char* v = std::getenv("KZG_HOST_TRACE")) ctx->host_trace = std::atoi(v) != 0;
     if (hipFuncSetAttribute(small_msm_kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_msm_lds_bytes()) == hipSuccess)
         ctx->small_lds_bytes = small_msm_lds_bytes();
     else
@@ -565,6 +618,12 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
         return;
     }
     hipSetDevice(ctx->device);
+    if (ctx->host_trace && ctx->trace_calls.load()) {
+        const double k = 1e-3 / (double)ctx->trace_calls.load();
+        std::fprintf(stderr, "[kzg host trace] %llu kzg_commit calls, us per call: wait-for-slot %.1f upload %.1f submit %.1f device %.1f collect %.1f\n",
+                     (unsigned long long)ctx->trace_calls.load(), k * ctx->trace_ns[0].load(), k * ctx->trace_ns[1].load(),
+                     k * ctx->trace_ns[2].load(), k * ctx->trace_ns[3].load(), k * ctx->trace_ns[4].load());
+    }
     for (auto& s : ctx->slots) {
         if (s.stream) hipStreamSynchronize(s.stream);
         free_slot_msm(s);
@@ -606,7 +665,8 @@ int kzg_srs_load_g1(kzg_ctx* ctx, const void* first_g1, size_t stride, size_t n)
         ctx->last_error.clear();
         return n ? multi_srs_load(ctx->multi, first_g1, stride, n) : KZG_ERR_INVALID_ARG;
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    quiesce(ctx, lk);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = srs_prepare(ctx, n);
     if (rc) return rc;
@@ -637,7 +697,8 @@ int kzg_srs_generate_g1(kzg_ctx* ctx, const uint8_t secret_be[32], uint64_t firs
         ctx->last_error.clear();
         return n ? multi_srs_generate(ctx->multi, secret_be, first, n) : KZG_ERR_INVALID_ARG;
     }
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    quiesce(ctx, lk);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = srs_prepare(ctx, n);
     if (rc) return rc;
@@ -680,11 +741,12 @@ static int finish_srs_from_level0(kzg_ctx* ctx, hipStream_t st, size_t n) {
 
 int kzg_srs_load_affine(kzg_ctx* ctx, const void* affine_xy, size_t n) {
     if (!ctx || !affine_xy || !n) return KZG_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::mutex> lk(ctx->mu);
     if (ctx->multi) {
         ctx->last_error.clear();
         return multi_srs_load_affine(ctx->multi, affine_xy, n);
     }
+    quiesce(ctx, lk);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = srs_prepare(ctx, n);
     if (rc) return rc;
@@ -700,11 +762,12 @@ int kzg_srs_load_affine(kzg_ctx* ctx, const void* affine_xy, size_t n) {
 int kzg_srs_load_compressed(kzg_ctx* ctx, const uint8_t* compressed, size_t n, size_t* bad_index) {
     if (!ctx || !compressed || !n) return KZG_ERR_INVALID_ARG;
     if (bad_index) *bad_index = (size_t)-1;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::mutex> lk(ctx->mu);
     if (ctx->multi) {
         ctx->last_error.clear();
         return multi_srs_load_compressed(ctx->multi, compressed, n, bad_index);
     }
+    quiesce(ctx, lk);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = srs_prepare(ctx, n);
     if (rc) return rc;
@@ -783,15 +846,63 @@ int kzg_srs_save(kzg_ctx* ctx, const char* path) {
     return ok ? KZG_OK : KZG_ERR_INVALID_ARG;
 }
 
+// on-curve check of the loaded points (host, spread over the cores): a corrupted cache must not commit silently
+static bool affine96_all_on_curve(const uint64_t* xy, size_t n, size_t* bad) {
+    size_t nthreads = std::thread::hardware_concurrency();
+    if (nthreads == 0) nthreads = 1;
+    if (nthreads > 16) nthreads = 16;
+    if (nthreads > n / 4096 + 1) nthreads = n / 4096 + 1;
+    std::vector<size_t> first_bad(nthreads, (size_t)-1);
+    hf::Fp four = hf::kOne + hf::kOne;
+    four = four + four;
+    auto work = [&](size_t t) {
+        for (size_t i = t; i < n; i += nthreads) {
+            hf::Fp x, y;
+            std::memcpy(&x, xy + 12 * i, 48);
+            std::memcpy(&y, xy + 12 * i + 6, 48);
+            if (x.is_zero() && y.is_zero()) continue;  // infinity
+            const bool ok = hf::geq(hf::kP, x) && !(x == hf::kP) && hf::geq(hf::kP, y) && !(y == hf::kP) &&
+                            hf::sqr(y) == hf::sqr(x) * x + four;
+            if (!ok) {
+                first_bad[t] = i;
+                return;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nthreads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    size_t worst = (size_t)-1;
+    for (size_t v : first_bad) worst = v < worst ? v : worst;
+    if (bad) *bad = worst;
+    return worst == (size_t)-1;
+}
+
 int kzg_srs_load_file(kzg_ctx* ctx, const char* path) {
     if (!ctx || !path) return KZG_ERR_INVALID_ARG;
+    auto fail = [&](const std::string& why) {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        ctx->last_error = why;
+        return (int)KZG_ERR_INVALID_ARG;
+    };
     FILE* f = std::fopen(path, "rb");
-    if (!f) return KZG_ERR_INVALID_ARG;
+    if (!f) return fail("cannot open the SRS file");
     SrsFileHeader h;
     bool ok = std::fread(&h, sizeof h, 1, f) == 1 && std::memcmp(h.magic, kSrsMagic, 8) == 0 && h.n > 0 && h.n <= 0x7fffffffu / 32;
+    if (ok) {  // the header's n is trusted only as far as the file is that long
+        ok = std::fseek(f, 0, SEEK_END) == 0;
+        const long end = ok ? std::ftell(f) : -1;
+        ok = ok && end >= 0 && (uint64_t)end == 128ull + 96ull * h.n && std::fseek(f, 128, SEEK_SET) == 0;
+    }
     std::vector<uint64_t> xy;
     if (ok) {
-        xy.resize((size_t)h.n * 12);
+        try {
+            xy.resize((size_t)h.n * 12);
+        } catch (const std::bad_alloc&) {  // nothing may unwind through the C-ABI
+            std::fclose(f);
+            return fail("out of host memory for the SRS file");
+        }
         ok = std::fread(xy.data(), 96, h.n, f) == h.n;
     }
     std::fclose(f);
@@ -801,10 +912,9 @@ int kzg_srs_load_file(kzg_ctx* ctx, const char* path) {
         affine96_compress(&xy[12 * ((size_t)h.n - 1)], b);
         ok = std::memcmp(a, h.first, 48) == 0 && std::memcmp(b, h.last, 48) == 0;
     }
-    if (!ok) {
-        ctx->last_error = "not a KZGSRS1 file, truncated, or its fingerprint does not match its content";
-        return KZG_ERR_INVALID_ARG;
-    }
+    if (!ok) return fail("not a KZGSRS1 file, truncated, or its fingerprint does not match its content");
+    size_t bad = 0;
+    if (!affine96_all_on_curve(xy.data(), (size_t)h.n, &bad)) return fail("SRS file: point " + std::to_string(bad) + " is not on the curve");
     return kzg_srs_load_affine(ctx, xy.data(), (size_t)h.n);
 }
 
@@ -827,12 +937,13 @@ int kzg_srs_read_g1(kzg_ctx* ctx, size_t index, size_t count, uint64_t* out_p1) 
 
 // ---- submit / wait ---------------------------------------------------------------------------
 
+// owned: the caller holds the slot through reserve_slot (SLOT_RESERVED) instead of finding it idle
 static int submit_commit_locked(kzg_ctx* ctx, int slot, const uint32_t* d_scalars, int is_mont, size_t n,
-                                bool tail_already_checked) {
+                                bool tail_already_checked, bool owned = false) {
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
     if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
     Slot& s = ctx->slots[slot];
-    if (s.kind != SLOT_IDLE) return KZG_ERR_BUSY;
+    if (s.kind != (owned ? SLOT_RESERVED : SLOT_IDLE)) return KZG_ERR_BUSY;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     s.timing = ctx->timing;
     s.has_quotient = false;
@@ -875,11 +986,11 @@ int kzg_commit_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n) {
 }
 
 static int submit_open_locked(kzg_ctx* ctx, int slot, const uint32_t* d_coeffs, size_t n, const uint64_t z[4],
-                              const uint64_t y[4]) {
+                              const uint64_t y[4], bool owned = false) {
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
     if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
     Slot& s = ctx->slots[slot];
-    if (s.kind != SLOT_IDLE) return KZG_ERR_BUSY;
+    if (s.kind != (owned ? SLOT_RESERVED : SLOT_IDLE)) return KZG_ERR_BUSY;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = ensure_poly(ctx, s, n);
     if (rc) return rc;
@@ -940,9 +1051,10 @@ static int wait_locked(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
         ctx->last_error = "kzg_wait on a slot that holds a batched job (use kzg_wait_batch / kzg_wait_open_batch)";
         return KZG_ERR_INVALID_ARG;  // the job stays in the slot
     }
+    if (s.kind == SLOT_RESERVED) return KZG_ERR_BUSY;  // a synchronous call on another thread owns it
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     SlotKind kind = s.kind;
-    s.kind = SLOT_IDLE;
+    slot_idle(ctx, s);
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
     if (kind == SLOT_TRIVIAL)  // nothing but flags may have been enqueued
         HIP_TRY(ctx, hipMemcpy(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost));
@@ -992,9 +1104,10 @@ static int wait_locked(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
 }
 
 int kzg_set_max_batch(kzg_ctx* ctx, size_t max_batch) {
-    KZG_SINGLE_DEVICE_ONLY(ctx);
     if (!ctx || max_batch == 0) return KZG_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->multi) return multi_set_max_batch(ctx->multi, max_batch);  // every device of the context
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    quiesce(ctx, lk);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = drain_all(ctx);
     if (rc) return rc;
@@ -1015,18 +1128,18 @@ int kzg_set_max_batch(kzg_ctx* ctx, size_t max_batch) {
     return rc;
 }
 
-size_t kzg_max_batch(const kzg_ctx* ctx) { return ctx ? ctx->max_batch : 0; }
+size_t kzg_max_batch(const kzg_ctx* ctx) {
+    if (ctx && ctx->multi) return kzg_max_batch(multi_kid(ctx->multi, 0));
+    return ctx ? ctx->max_batch : 0;
+}
 
-int kzg_commit_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch,
-                            size_t stride_coeffs) {
-    KZG_SINGLE_DEVICE_ONLY(ctx);
-    if (!ctx || !d_coeffs || n == 0 || batch == 0 || stride_coeffs < n || n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+static int commit_batch_submit_locked(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch,
+                                      size_t stride_coeffs, bool owned = false) {
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
     if (slot < 0 || slot >= kNumSlots || batch > ctx->max_batch) return KZG_ERR_INVALID_ARG;
     if (n > ctx->n) return KZG_ERR_DEGREE_TOO_HIGH;  // batches take truncated polynomials only
     Slot& s = ctx->slots[slot];
-    if (s.kind != SLOT_IDLE) return KZG_ERR_BUSY;
+    if (s.kind != (owned ? SLOT_RESERVED : SLOT_IDLE)) return KZG_ERR_BUSY;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     s.timing = ctx->timing;
     s.has_quotient = false;
@@ -1043,15 +1156,21 @@ int kzg_commit_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t
     return KZG_OK;
 }
 
-int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
+int kzg_commit_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch,
+                            size_t stride_coeffs) {
     KZG_SINGLE_DEVICE_ONLY(ctx);
-    if (!ctx || !out_p1s) return KZG_ERR_INVALID_ARG;
+    if (!ctx || !d_coeffs || n == 0 || batch == 0 || stride_coeffs < n || n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    return commit_batch_submit_locked(ctx, slot, d_coeffs, n, batch, stride_coeffs);
+}
+
+// out_stride: u64 words between consecutive results (18 = packed)
+static int wait_batch_locked(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch, size_t out_stride = 18) {
     if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
     Slot& s = ctx->slots[slot];
     if (s.kind != SLOT_COMMIT_BATCH || s.job_batch != batch) return KZG_ERR_INVALID_ARG;  // the job stays in the slot
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    s.kind = SLOT_IDLE;
+    slot_idle(ctx, s);
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
     if (s.timing) {
         float ms = 0;
@@ -1064,9 +1183,9 @@ int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
     }
     // host tails of the batch in parallel (each is ~150 point operations and one inversion)
     const uint32_t B = s.job_batch;
-    const uint32_t nthreads = B < 8 ? B : 8;
+    const uint32_t nthreads = B <= 2 ? 1 : (B < 8 ? B : 8);  // (a thread costs ~50 us to start, a tail ~100)
     auto work = [&](uint32_t t) {
-        for (uint32_t p = t; p < B; p += nthreads) write_p1(out_p1s + 18 * (size_t)p, finish_msm(ctx, s, p, B));
+        for (uint32_t p = t; p < B; p += nthreads) write_p1(out_p1s + out_stride * (size_t)p, finish_msm(ctx, s, p, B));
     };
     if (nthreads <= 1) {
         work(0);
@@ -1079,20 +1198,26 @@ int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
     return KZG_OK;
 }
 
+int kzg_wait_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t batch) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
+    if (!ctx || !out_p1s) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return wait_batch_locked(ctx, slot, out_p1s, batch);
+}
+
 // Batched Evaluation::generate_proof: one quotient scan per polynomial (each with its own z, y), then
 // ONE batched MSM over the `batch` quotients.
-int kzg_open_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch, size_t stride_coeffs,
-                          const uint64_t* zs, const uint64_t* ys) {
-    KZG_SINGLE_DEVICE_ONLY(ctx);
-    if (!ctx || !d_coeffs || !zs || !ys || n < 2 || batch == 0 || stride_coeffs < n || n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+static int open_batch_submit_locked(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch, size_t stride_coeffs,
+                                    const uint64_t* zs, const uint64_t* ys, bool owned = false) {
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
     if (slot < 0 || slot >= kNumSlots || batch > ctx->max_batch) return KZG_ERR_INVALID_ARG;
     if (n - 1 > ctx->n) return KZG_ERR_DEGREE_TOO_HIGH;  // batches take truncated polynomials only
     Slot& s = ctx->slots[slot];
-    if (s.kind != SLOT_IDLE) return KZG_ERR_BUSY;
+    if (s.kind != (owned ? SLOT_RESERVED : SLOT_IDLE)) return KZG_ERR_BUSY;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = ensure_poly(ctx, s, n * batch);
+    // (an owned slot's coefficients sit in its own staging buffer, which ensure_poly must not reallocate now: the
+    // owner sized it before the upload)
+    int rc = owned ? KZG_OK : ensure_poly(ctx, s, n * batch);
     if (rc) return rc;
     if (s.bsmall_cap < batch) {
         HIP_TRY(ctx, hipStreamSynchronize(s.stream));
@@ -1132,16 +1257,22 @@ int kzg_open_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n
     return KZG_OK;
 }
 
-int kzg_wait_open_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, int* statuses, size_t batch) {
+int kzg_open_batch_submit(kzg_ctx* ctx, int slot, const void* d_coeffs, size_t n, size_t batch, size_t stride_coeffs,
+                          const uint64_t* zs, const uint64_t* ys) {
     KZG_SINGLE_DEVICE_ONLY(ctx);
-    if (!ctx || !out_p1s || !statuses) return KZG_ERR_INVALID_ARG;
+    if (!ctx || !d_coeffs || !zs || !ys || n < 2 || batch == 0 || stride_coeffs < n || n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    return open_batch_submit_locked(ctx, slot, d_coeffs, n, batch, stride_coeffs, zs, ys);
+}
+
+static int wait_open_batch_locked(kzg_ctx* ctx, int slot, uint64_t* out_p1s, int* statuses, size_t batch, size_t out_stride = 18,
+                                  size_t status_stride = 1) {
     if (slot < 0 || slot >= kNumSlots) return KZG_ERR_INVALID_ARG;
     Slot& s = ctx->slots[slot];
     if (s.kind != SLOT_OPEN_BATCH || s.job_batch != batch || s.open_ys.size() != 8 * batch)
         return KZG_ERR_INVALID_ARG;  // the job stays in the slot
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    s.kind = SLOT_IDLE;
+    slot_idle(ctx, s);
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
     if (s.timing) {
         float ms = 0;
@@ -1157,19 +1288,27 @@ int kzg_wait_open_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, int* statuses
     for (uint32_t p = 0; p < B; p++) {
         const uint32_t* hs = s.h_bsmall + p * 32;
         const uint32_t* y = s.open_ys.data() + 8 * p;
-        uint64_t* out = out_p1s + 18 * (size_t)p;
+        uint64_t* out = out_p1s + out_stride * (size_t)p;
+        int& status = statuses[status_stride * (size_t)p];
         // reference order: divide_by_root's two errors (src/polynomial.rs:159-167, 184-192)
         if (!(hs[0] & 1u)) {  // constant polynomial after truncation
-            if (std::memcmp(hs + 16, y, 32) != 0) statuses[p] = KZG_ERR_CONSTANT_POLY;
-            else { statuses[p] = KZG_OK; write_p1(out, inf); }
+            if (std::memcmp(hs + 16, y, 32) != 0) status = KZG_ERR_CONSTANT_POLY;
+            else { status = KZG_OK; write_p1(out, inf); }
             continue;
         }
-        if (std::memcmp(hs + 8, y, 32) != 0) { statuses[p] = KZG_ERR_REMAINDER; continue; }
-        statuses[p] = KZG_OK;
+        if (std::memcmp(hs + 8, y, 32) != 0) { status = KZG_ERR_REMAINDER; continue; }
+        status = KZG_OK;
         write_p1(out, finish_msm(ctx, s, p, B));
     }
     s.open_ys.clear();
     return KZG_OK;
+}
+
+int kzg_wait_open_batch(kzg_ctx* ctx, int slot, uint64_t* out_p1s, int* statuses, size_t batch) {
+    KZG_SINGLE_DEVICE_ONLY(ctx);
+    if (!ctx || !out_p1s || !statuses) return KZG_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    return wait_open_batch_locked(ctx, slot, out_p1s, statuses, batch);
 }
 
 int kzg_wait(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
@@ -1180,34 +1319,70 @@ int kzg_wait(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
 }
 
 // ---- synchronous host-pointer entry points (what the Rust shim calls) ---------------------------
+// The context mutex is held only while a step touches shared state (slot table, enqueue order), never across the
+// upload or the wait: the reference's callers are threads of `cargo test` (src/lib.rs:53, 66, 91), and N of them now
+// occupy N slots whose jobs pipeline exactly like explicit kzg_*_submit calls.
 
-static int find_idle_slot(kzg_ctx* ctx) {
-    for (int i = 0; i < kNumSlots; i++)
-        if (ctx->slots[i].kind == SLOT_IDLE) return i;
-    return -1;
+// pageable host memory -> the slot's staging buffer, on the slot's stream, without the mutex
+static int upload_unlocked(kzg_ctx* ctx, std::unique_lock<std::mutex>& lk, Slot& s, size_t dst_coeff, const void* src, size_t coeffs) {
+    if (!coeffs) return KZG_OK;
+    lk.unlock();
+    const hipError_t e = hipMemcpyAsync(s.d_stage + dst_coeff * 8, src, coeffs * 32, hipMemcpyHostToDevice, s.stream);
+    lk.lock();
+    if (e != hipSuccess) {
+        ctx->last_error = std::string("hipMemcpyAsync (coefficients): ") + hipGetErrorString(e);
+        return KZG_ERR_HIP;
+    }
+    return KZG_OK;
 }
+// waits for the slot's job outside the mutex (kinds that recorded `done`), then collects it
+static void await_unlocked(std::unique_lock<std::mutex>& lk, Slot& s) {
+    if (s.kind == SLOT_TRIVIAL || s.kind == SLOT_RESERVED || s.kind == SLOT_IDLE) return;
+    lk.unlock();
+    (void)hipEventSynchronize(s.done);
+    lk.lock();
+}
+
+struct HostTrace {  // phase stopwatch of one synchronous call
+    kzg_ctx* ctx;
+    std::chrono::steady_clock::time_point t;
+    explicit HostTrace(kzg_ctx* c) : ctx(c) { if (c->host_trace) t = std::chrono::steady_clock::now(); }
+    void mark(int phase) {
+        if (!ctx->host_trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        ctx->trace_ns[phase] += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(now - t).count();
+        t = now;
+    }
+};
 
 static int commit_host(kzg_ctx* ctx, const void* scalars, int is_mont, size_t n, uint64_t out_p1[18]) {
     if (!ctx || !out_p1 || (!scalars && n)) return KZG_ERR_INVALID_ARG;
     if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (ctx->multi) {
-        ctx->last_error.clear();
-        return multi_commit(ctx->multi, scalars, is_mont, n, out_p1);
-    }
+    if (ctx->multi) return multi_commit(ctx->multi, scalars, is_mont, n, out_p1);
+    HostTrace tr(ctx);
+    std::unique_lock<std::mutex> lk(ctx->mu);
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
-    int slot = find_idle_slot(ctx);
-    if (slot < 0) return KZG_ERR_BUSY;
-    Slot& s = ctx->slots[slot];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (n > ctx->n && host_tail_nonzero((const uint64_t*)scalars, ctx->n, n)) return KZG_ERR_DEGREE_TOO_HIGH;
-    size_t n_dev = n < ctx->n ? n : ctx->n;
+    const int slot = reserve_slot(ctx, lk, true);
+    if (slot < 0) return KZG_ERR_BUSY;
+    Slot& s = ctx->slots[slot];
+    const size_t n_dev = n < ctx->n ? n : ctx->n;
     int rc = ensure_poly(ctx, s, n_dev);
-    if (rc) return rc;
-    if (n_dev) HIP_TRY(ctx, hipMemcpyAsync(s.d_stage, scalars, n_dev * 32, hipMemcpyHostToDevice, s.stream));
-    rc = submit_commit_locked(ctx, slot, s.d_stage, is_mont, n_dev, true);
-    if (rc) return rc;
-    return wait_locked(ctx, slot, out_p1);
+    tr.mark(0);
+    if (rc == KZG_OK) rc = upload_unlocked(ctx, lk, s, 0, scalars, n_dev);
+    tr.mark(1);
+    if (rc == KZG_OK) rc = submit_commit_locked(ctx, slot, s.d_stage, is_mont, n_dev, true, true);
+    tr.mark(2);
+    if (rc == KZG_OK) {
+        await_unlocked(lk, s);
+        tr.mark(3);
+        rc = wait_locked(ctx, slot, out_p1);
+        tr.mark(4);
+    }
+    release_owned(ctx, slot);
+    ctx->trace_calls++;
+    return rc;
 }
 
 int kzg_commit(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, uint64_t out_p1[18]) {
@@ -1221,22 +1396,203 @@ int kzg_open(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4]
              uint64_t out_p1[18]) {
     if (!ctx || !out_p1 || !z || !y || (!coeffs && n)) return KZG_ERR_INVALID_ARG;
     if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    if (ctx->multi) {
-        ctx->last_error.clear();
-        return multi_open(ctx->multi, coeffs, n, z, y, out_p1);
-    }
+    if (ctx->multi) return multi_open(ctx->multi, coeffs, n, z, y, out_p1);
+    std::unique_lock<std::mutex> lk(ctx->mu);
     if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
-    int slot = find_idle_slot(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int slot = reserve_slot(ctx, lk, true);
     if (slot < 0) return KZG_ERR_BUSY;
     Slot& s = ctx->slots[slot];
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rc = ensure_poly(ctx, s, n);
-    if (rc) return rc;
-    if (n) HIP_TRY(ctx, hipMemcpyAsync(s.d_stage, coeffs, n * 32, hipMemcpyHostToDevice, s.stream));
-    rc = submit_open_locked(ctx, slot, s.d_stage, n, z, y);
-    if (rc) return rc;
-    return wait_locked(ctx, slot, out_p1);
+    if (rc == KZG_OK) rc = upload_unlocked(ctx, lk, s, 0, coeffs, n);
+    if (rc == KZG_OK) rc = submit_open_locked(ctx, slot, s.d_stage, n, z, y, true);
+    if (rc == KZG_OK) {
+        await_unlocked(lk, s);
+        rc = wait_locked(ctx, slot, out_p1);
+    }
+    release_owned(ctx, slot);
+    return rc;
+}
+
+// ---- host-pointer batches (BASELINE config 5: many openings against one SRS) ----------------------------------------
+namespace {
+struct BatchInFlight {
+    int slot;
+    size_t first_poly, polys;  // position in the caller's (first, step, count) sequence
+};
+// polynomials per submit: four or more sub-batches per call, so that the upload of one overlaps the kernels of the
+// previous ones (a degree-2^20 polynomial is 32 MiB of pageable host memory), each at most max_batch polynomials
+size_t host_batch_chunk(const kzg_ctx* ctx, size_t count) {
+    size_t chunk = (count + 3) / 4;
+    if (chunk > ctx->max_batch) chunk = ctx->max_batch;
+    return chunk < 1 ? 1 : chunk;
+}
+}  // namespace
+
+}  // extern "C"
+
+namespace kzg {
+
+void ctx_set_raw_partials(kzg_ctx* ctx, bool raw) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->raw_partials = raw;
+}
+
+// shared body of the two host-pointer batches: zs == nullptr -> commitments
+static int batch_host(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, size_t stride, size_t first, size_t step, size_t count,
+                      const uint64_t* zs, const uint64_t* ys, uint64_t* out_p1s, int* statuses) {
+    if (!count) return KZG_OK;
+    const bool opening = zs != nullptr;
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
+    if ((opening ? n - 1 : n) > ctx->n) return KZG_ERR_DEGREE_TOO_HIGH;  // batches take truncated polynomials only
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t chunk = host_batch_chunk(ctx, count);
+    std::deque<BatchInFlight> fifo;
+    auto collect_oldest = [&]() -> int {
+        const BatchInFlight b = fifo.front();
+        fifo.pop_front();
+        Slot& s = ctx->slots[b.slot];
+        await_unlocked(lk, s);
+        uint64_t* out = out_p1s + 18 * (first + b.first_poly * step);
+        const int r = opening ? wait_open_batch_locked(ctx, b.slot, out, statuses + (first + b.first_poly * step), b.polys, 18 * step, step)
+                              : wait_batch_locked(ctx, b.slot, out, b.polys, 18 * step);
+        release_owned(ctx, b.slot);
+        return r;
+    };
+    int rc = KZG_OK;
+    std::vector<uint64_t> zc, yc;
+    for (size_t at = 0; at < count && rc == KZG_OK; at += chunk) {
+        const size_t polys = count - at < chunk ? count - at : chunk;
+        int slot = reserve_slot(ctx, lk, false);
+        while (slot < 0 && rc == KZG_OK) {
+            if (!fifo.empty()) rc = collect_oldest();           // my own oldest sub-batch frees a slot
+            else if ((slot = reserve_slot(ctx, lk, true)) < 0) rc = KZG_ERR_BUSY;  // other callers hold them all
+            if (slot < 0 && rc == KZG_OK) slot = reserve_slot(ctx, lk, false);
+        }
+        if (rc != KZG_OK) {
+            if (slot >= 0) release_owned(ctx, slot);
+            break;
+        }
+        Slot& s = ctx->slots[slot];
+        rc = ensure_poly(ctx, s, n * polys);
+        for (size_t q = 0; q < polys && rc == KZG_OK; q++)
+            rc = upload_unlocked(ctx, lk, s, q * n, coeffs + (first + (at + q) * step) * stride * 4, n);
+        if (rc == KZG_OK) {
+            if (opening) {
+                zc.resize(4 * polys);
+                yc.resize(4 * polys);
+                for (size_t q = 0; q < polys; q++) {
+                    std::memcpy(&zc[4 * q], zs + 4 * (first + (at + q) * step), 32);
+                    std::memcpy(&yc[4 * q], ys + 4 * (first + (at + q) * step), 32);
+                }
+                rc = open_batch_submit_locked(ctx, slot, s.d_stage, n, polys, n, zc.data(), yc.data(), true);
+            } else {
+                rc = commit_batch_submit_locked(ctx, slot, s.d_stage, n, polys, n, true);
+            }
+        }
+        if (rc != KZG_OK) {
+            release_owned(ctx, slot);
+            break;
+        }
+        fifo.push_back({slot, at, polys});
+    }
+    while (!fifo.empty()) {
+        const int r = collect_oldest();
+        if (rc == KZG_OK) rc = r;
+    }
+    return rc;
+}
+
+int ctx_commit_batch_host(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, size_t stride_coeffs, size_t first, size_t step,
+                          size_t count, uint64_t* out_p1s) {
+    return batch_host(ctx, coeffs, n, stride_coeffs, first, step, count, nullptr, nullptr, out_p1s, nullptr);
+}
+int ctx_open_batch_host(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, size_t stride_coeffs, size_t first, size_t step,
+                        size_t count, const uint64_t* zs, const uint64_t* ys, uint64_t* out_p1s, int* statuses) {
+    return batch_host(ctx, coeffs, n, stride_coeffs, first, step, count, zs, ys, out_p1s, statuses);
+}
+
+// ---- one device's share of a range-sharded opening: the slice is staged once (multi.hip) ----------------------------
+int ctx_open_slice_begin(kzg_ctx* ctx, const uint64_t* slice, size_t len, const uint64_t z[4], uint64_t out_h[4], int* slot_out) {
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    if (!ctx->n || !ctx->slots_ready) return KZG_ERR_NO_SRS;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int slot = reserve_slot(ctx, lk, true);
+    if (slot < 0) return KZG_ERR_BUSY;
+    Slot& s = ctx->slots[slot];
+    int rc = ensure_poly(ctx, s, len + 1);
+    if (rc == KZG_OK) rc = upload_unlocked(ctx, lk, s, 0, slice, len);
+    if (rc == KZG_OK) {
+        lk.unlock();
+        uint32_t zw[8];
+        std::memcpy(zw, z, 32);
+        hipError_t e = hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream);
+        PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
+        launch_quotient(s.stream, s.d_stage, (uint32_t)len, zw, nullptr, sc);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
+        lk.lock();
+        if (e != hipSuccess) {
+            ctx->last_error = std::string("slice evaluation: ") + hipGetErrorString(e);
+            rc = KZG_ERR_HIP;
+        }
+    }
+    if (rc != KZG_OK) {
+        release_owned(ctx, slot);
+        return rc;
+    }
+    std::memcpy(out_h, s.h_small + 8, 32);
+    *slot_out = slot;
+    return KZG_OK;
+}
+
+int ctx_open_slice_finish(kzg_ctx* ctx, int slot, size_t len, const uint64_t carry[4], const uint64_t z[4],
+                          const uint64_t start[4], uint64_t out_p1[18]) {
+    std::unique_lock<std::mutex> lk(ctx->mu);
+    Slot& s = ctx->slots[slot];
+    int rc = KZG_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) rc = KZG_ERR_HIP;
+    if (rc == KZG_OK) rc = upload_unlocked(ctx, lk, s, len, carry, 1);  // the carry as one more top coefficient
+    if (rc == KZG_OK) rc = submit_open_locked(ctx, slot, s.d_stage, len + 1, z, start, true);
+    if (rc == KZG_OK) {
+        await_unlocked(lk, s);
+        rc = wait_locked(ctx, slot, out_p1);
+    }
+    release_owned(ctx, slot);
+    return rc;
+}
+
+void ctx_open_slice_abort(kzg_ctx* ctx, int slot) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    release_owned(ctx, slot);
+}
+
+}  // namespace kzg
+
+extern "C" {
+
+int kzg_commit_batch(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, size_t batch, size_t stride_coeffs, uint64_t* out_p1s) {
+    if (!ctx || (!coeffs && batch) || (!out_p1s && batch) || n == 0 || stride_coeffs < n || n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
+    if (ctx->multi) return multi_commit_batch(ctx->multi, coeffs, n, batch, stride_coeffs, out_p1s);
+    return ctx_commit_batch_host(ctx, coeffs, n, stride_coeffs, 0, 1, batch, out_p1s);
+}
+
+int kzg_open_batch(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, size_t batch, size_t stride_coeffs, const uint64_t* zs,
+                   const uint64_t* ys, uint64_t* out_p1s, int* statuses) {
+    if (!ctx || ((!coeffs || !zs || !ys || !out_p1s || !statuses) && batch) || stride_coeffs < n || n > kMaxCoefficients)
+        return KZG_ERR_INVALID_ARG;
+    if (n < 2) {  // empty and constant polynomials: the single-opening path knows their rules (src/polynomial.rs:138-167)
+        for (size_t p = 0; p < batch; p++) {
+            const int rc = kzg_open(ctx, coeffs + p * stride_coeffs * 4, n, zs + 4 * p, ys + 4 * p, out_p1s + 18 * p);
+            if (rc != KZG_OK && rc != KZG_ERR_CONSTANT_POLY && rc != KZG_ERR_REMAINDER && rc != KZG_ERR_DEGREE_TOO_HIGH) return rc;
+            statuses[p] = rc;
+        }
+        return KZG_OK;
+    }
+    if (ctx->multi) return multi_open_batch(ctx->multi, coeffs, n, batch, stride_coeffs, zs, ys, out_p1s, statuses);
+    return ctx_open_batch_host(ctx, coeffs, n, stride_coeffs, 0, 1, batch, zs, ys, out_p1s, statuses);
 }
 
 int kzg_quotient(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t z[4], const uint64_t y[4],
@@ -1244,10 +1600,11 @@ int kzg_quotient(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t 
     if (!ctx || !z || !y || !out_qn || (!coeffs && n) || (!out_q && n > 1)) return KZG_ERR_INVALID_ARG;
     if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     if (ctx->multi) return kzg_quotient(multi_kid(ctx->multi, 0), coeffs, n, z, y, out_q, out_qn);  // needs no SRS
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::mutex> lk(ctx->mu);
     *out_qn = 0;
-    int slot = find_idle_slot(ctx);
+    const int slot = reserve_slot(ctx, lk, true);
     if (slot < 0) return KZG_ERR_BUSY;
+    SlotLease lease{ctx, slot};
     Slot& s = ctx->slots[slot];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rcb = ensure_slot_basics(ctx, s);  // quotient does not need an SRS
@@ -1282,11 +1639,12 @@ int kzg_evaluate(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t 
     if (!ctx || !z || !out_y || (!coeffs && n)) return KZG_ERR_INVALID_ARG;
     if (n > kMaxCoefficients) return KZG_ERR_INVALID_ARG;
     if (ctx->multi) return kzg_evaluate(multi_kid(ctx->multi, 0), coeffs, n, z, out_y);  // needs no SRS
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::unique_lock<std::mutex> lk(ctx->mu);
     std::memset(out_y, 0, 32);
     if (n == 0) return KZG_OK;
-    int slot = find_idle_slot(ctx);
+    const int slot = reserve_slot(ctx, lk, true);
     if (slot < 0) return KZG_ERR_BUSY;
+    SlotLease lease{ctx, slot};
     Slot& s = ctx->slots[slot];
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int rcb = ensure_slot_basics(ctx, s);

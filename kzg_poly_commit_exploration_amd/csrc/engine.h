@@ -151,8 +151,30 @@ void launch_affine_to_p1(hipStream_t s, const void* d_affine, uint32_t n, void* 
 #include <string>
 struct kzg_ctx;
 namespace kzg {
+// ---- api.hip: single-device pieces the multi-device context drives (never exported) ------------------------------
+// A kid of a range-split context returns its partial sums UN-normalised (Jacobian X*ZZ, Y*ZZZ, ZZ of the XYZZ total:
+// two products instead of an inversion); the parent normalises once after the K-1 additions.
+void ctx_set_raw_partials(kzg_ctx* ctx, bool raw);
+// Host-pointer batches on ONE device: polynomial i (i < count) is the caller's polynomial first + i * step, its n
+// coefficients at coeffs + (first + i * step) * stride_coeffs blst_fr values, its result at out_p1s + 18 * (first + i *
+// step) (and statuses[first + i * step]).  Sub-batches flow through the context's stream slots so that the upload of
+// one overlaps the kernels of the previous ones.
+int ctx_commit_batch_host(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, size_t stride_coeffs, size_t first, size_t step,
+                          size_t count, uint64_t* out_p1s);
+int ctx_open_batch_host(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, size_t stride_coeffs, size_t first, size_t step,
+                        size_t count, const uint64_t* zs, const uint64_t* ys, uint64_t* out_p1s, int* statuses);
+// One device's share of a range-sharded opening (multi.hip): the slice is uploaded ONCE.  begin: slice -> the slot's
+// staging buffer, H = sum_i slice[i] z^i (the quotient scan without output); finish: the carry becomes coefficient
+// `len` of the staged slice, which is opened at z with claimed value `start`.  The slot stays reserved in between;
+// ctx_open_slice_abort releases it when the recurrence on the host refuses the opening.
+int ctx_open_slice_begin(kzg_ctx* ctx, const uint64_t* slice, size_t len, const uint64_t z[4], uint64_t out_h[4], int* slot_out);
+int ctx_open_slice_finish(kzg_ctx* ctx, int slot, size_t len, const uint64_t carry[4], const uint64_t z[4],
+                          const uint64_t start[4], uint64_t out_p1[18]);
+void ctx_open_slice_abort(kzg_ctx* ctx, int slot);
+
 struct MultiState;
-int multi_create(const int* devices, int ndev, MultiState** out, std::string& err);
+enum : uint32_t { kMultiRange = 0, kMultiReplicate = 1 };
+int multi_create(const int* devices, int ndev, uint32_t mode, MultiState** out, std::string& err);
 void multi_destroy(MultiState* m);
 size_t multi_srs_len(const MultiState* m);
 int multi_num_devices(const MultiState* m);
@@ -166,6 +188,11 @@ int multi_srs_load_compressed(MultiState* m, const uint8_t* compressed, size_t n
 int multi_srs_read(MultiState* m, size_t index, size_t count, uint64_t* out_p1);
 int multi_commit(MultiState* m, const void* scalars, int is_mont, size_t n, uint64_t out_p1[18]);
 int multi_open(MultiState* m, const uint64_t* coeffs, size_t n, const uint64_t z[4], const uint64_t y[4], uint64_t out_p1[18]);
+int multi_commit_batch(MultiState* m, const uint64_t* coeffs, size_t n, size_t batch, size_t stride_coeffs, uint64_t* out_p1s);
+int multi_open_batch(MultiState* m, const uint64_t* coeffs, size_t n, size_t batch, size_t stride_coeffs, const uint64_t* zs,
+                     const uint64_t* ys, uint64_t* out_p1s, int* statuses);
+int multi_set_max_batch(MultiState* m, size_t max_batch);
+uint32_t multi_mode(const MultiState* m);
 
 // ---- poly_kernels.hip -------------------------------------------------------------------
 struct PolyScratch {

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <cstring>
 #include <initializer_list>
+#include <vector>
 
 #include "field30_inv.hip.h"
 
@@ -344,6 +345,37 @@ inline PX px_add(const PX& a, const PX& b) {  // add-2008-s, complete: handles i
     r.zz = a.zz * b.zz * p2;
     r.zzz = a.zzz * b.zzz * p3;
     return r;
+}
+// XYZZ -> Jacobian without an inversion: Z = ZZ gives Z^2 = ZZ^2, Z^3 = ZZ^3 = ZZZ^2, so (X ZZ, Y ZZZ, ZZ).
+// The un-normalised partial sum a device of a range-split context hands to the exchange (multi.hip).
+inline P1 px_to_jacobian(const PX& p) {
+    if (p.is_inf()) return p1_inf();
+    P1 r;
+    r.x = p.x * p.zz;
+    r.y = p.y * p.zzz;
+    r.z = p.zz;
+    return r;
+}
+// normalises k Jacobian points with ONE inversion (Montgomery's trick over the Z coordinates; infinities skipped)
+inline void p1_normalize_many(P1* pts, size_t k) {
+    std::vector<Fp> prefix(k);
+    Fp run = kOne;
+    for (size_t i = 0; i < k; i++) {
+        prefix[i] = run;
+        if (!pts[i].is_inf()) run = run * pts[i].z;
+    }
+    Fp inv_run = inv(run);
+    for (size_t i = k; i-- > 0;) {
+        if (pts[i].is_inf()) {
+            pts[i] = p1_inf();
+            continue;
+        }
+        const Fp zi = inv_run * prefix[i], zi2 = sqr(zi);
+        inv_run = inv_run * pts[i].z;
+        pts[i].x = pts[i].x * zi2;
+        pts[i].y = pts[i].y * zi2 * zi;
+        pts[i].z = kOne;
+    }
 }
 inline P1 px_normalize(const PX& p) {  // affine with z = R, or all-zero for inf: one inversion for both denominators
     if (p.is_inf()) return p1_inf();

@@ -33,7 +33,24 @@ def main():
     for _ in range(reps):
         eng.open_limbs(c, z, y)
     t_open = (time.perf_counter() - t0) / reps
-    print(json.dumps({"degree": n - 1, "kzg_commit_host_pointer_ms": round(t_commit * 1e3, 3),
+    import threading
+
+    threaded = {}
+    for nthreads in (2, 3, 4):
+        per = 12
+
+        def worker():
+            for _ in range(per):
+                eng.commit_limbs(c)
+
+        ths = [threading.Thread(target=worker) for _ in range(nthreads)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        threaded["commitments_per_s_%d_threads" % nthreads] = round(nthreads * per / (time.perf_counter() - t0), 1)
+    print(json.dumps({"degree": n - 1, "kzg_commit_host_pointer_ms": round(t_commit * 1e3, 3), **threaded,
                       "commitments_per_s_pcie_inclusive": round(1 / t_commit, 1),
                       "kzg_open_host_pointer_ms": round(t_open * 1e3, 3),
                       "opening_proofs_per_s_pcie_inclusive": round(1 / t_open, 1),

@@ -484,6 +484,52 @@ def test_concurrent_host_threads_share_one_context(engines, oracle, golden):
         other.close()
 
 
+def test_host_pointer_callers_overlap_on_the_stream_slots(engines, oracle, golden):
+    """kzg_commit from three host threads at degree 2^20: the calls hold the context mutex only while they touch the
+    slot table, so their jobs occupy three slots and pipeline (sort and reduction of one in the shadow of another's
+    accumulation, uploads beside kernels).  Wall time of 3 x 6 threaded calls must be well below 18 serial ones."""
+    import threading
+    import time
+
+    d = 1 << 20
+    eng = engines.bench_srs(d + 1)
+    c, _, _ = _bench_poly(oracle, d)
+    want = _case(golden, d)["commit"]
+    assert eng.commit_limbs(c).compress().hex() == want  # warm-up (staging buffers, clocks)
+    reps = 6
+    t0 = time.perf_counter()
+    for _ in range(3 * reps):
+        assert eng.commit_limbs(c).compress().hex() == want
+    serial = time.perf_counter() - t0
+    errors = []
+
+    def worker():
+        try:
+            for _ in range(reps):
+                if eng.commit_limbs(c).compress().hex() != want:
+                    errors.append("commit")
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker) for _ in range(3)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    threaded = time.perf_counter() - t0
+    assert not errors, errors[:3]
+    print("host-pointer commits at 2^20: serial %.1f ms, 3 threads %.1f ms per call" % (1e3 * serial / (3 * reps), 1e3 * threaded / (3 * reps)))
+    assert threaded < 0.85 * serial, (threaded, serial)
+    # a fifth and sixth caller simply wait for a slot (they used to wait for the mutex): no KZG_ERR_BUSY
+    threads = [threading.Thread(target=worker) for _ in range(6)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors[:3]
+
+
 def test_zero_heavy_scalars_fill_the_accumulation_lanes(engines, oracle, golden):
     """The segment length follows the number of non-zero digits counted on the device: i128-style coefficients
     leave the upper windows empty, a sparse polynomial most of them; results and reference counts must agree."""
@@ -999,6 +1045,203 @@ def test_multi_device_context_degree_2_20(oracle, golden):
         eng.srs_generate(secret, d + 1)
         assert eng.commit_limbs(c).compress().hex() == case["commit"]
         assert eng.open_limbs(c, z, y).compress().hex() == case["proof"]
+    finally:
+        eng.close()
+
+
+def _eight_devices():
+    """the 8-GPU node's devices when they are visible, otherwise eight virtual devices on GPU 0"""
+    import torch
+
+    ndev = torch.cuda.device_count()
+    return list(range(8)) if ndev >= 8 else [0] * 8
+
+
+def test_config4_degree_2_22_sharded_over_eight_slices(oracle, golden):
+    """BASELINE config 4 at its own size through ONE library entry point: a degree-2^22 commitment and opening on a
+    context of 8 devices (8 x 2^19 SRS points; virtual slices of one GPU when the box has one), partial sums through
+    the exchange, against the golden vectors derived from the known secret."""
+    secret = bytes.fromhex(golden["secret_be"])
+    d = 1 << 22
+    c, z, y = _bench_poly(oracle, d)
+    case = _case(golden, d)
+    devs = _eight_devices()
+    eng = K.Engine(devices=devs)
+    try:
+        eng.srs_generate(secret, d + 1)
+        assert eng.num_devices() == 8 and eng.srs_len() == d + 1
+        assert oracle.p1_compress(eng.srs_read(d, 1)[0]).hex() == golden["srs_g1"][str(d)]
+        assert eng.commit_limbs(c).compress().hex() == case["commit"]
+        assert eng.open_limbs(c, z, y).compress().hex() == case["proof"]
+        with pytest.raises(K.KzgError) as ei:
+            eng.open_limbs(c, z, K.Scalar(y.v ^ 1))
+        assert ei.value.status == K.KZG_ERR_REMAINDER
+        if len(set(devs)) == 8:
+            assert eng.rccl_exchanges() >= 2
+    finally:
+        eng.close()
+
+
+def test_config4_exchange_over_rccl_with_raw_partials(oracle, golden, monkeypatch):
+    """The same sharded calls with the partial sums forced through the RCCL leg (communicator of one on a one-GPU box):
+    un-normalised Jacobian partials up, ncclAllGather, down, K-1 additions, one normalisation; also a batch of
+    commitments sharded by range (one exchange for the whole batch)."""
+    monkeypatch.setenv("KZG_MULTI_FORCE_RCCL", "1")
+    secret = bytes.fromhex(golden["secret_be"])
+    d = 2500
+    c, z, y = _bench_poly(oracle, d)
+    case = _case(golden, d)
+    eng = K.Engine(devices=[0])
+    try:
+        eng.srs_generate(secret, d + 1)
+        eng.set_max_batch(4)
+        polys = [c] + [K.scalars_to_limbs([(7 * k + i) % 1000 for i in range(d + 1)]) for k in range(1, 6)]
+        got = eng.commit_batch_host(polys)
+        assert got[0].compress().hex() == case["commit"]
+        for k in range(1, 6):
+            assert got[k].compress() == eng.commit_limbs(polys[k]).compress()
+        assert eng.rccl_exchanges() == 1 + 5
+    finally:
+        eng.close()
+
+
+def test_range_split_context_batches(engines, oracle, golden):
+    """kzg_commit_batch / kzg_open_batch on a range-split context of 3 virtual slices: every polynomial sharded,
+    results equal to the single-device engine's, per-polynomial statuses kept."""
+    secret = bytes.fromhex(golden["secret_be"])
+    d = 2500
+    c, z, y = _bench_poly(oracle, d)
+    case = _case(golden, d)
+    single = engines.bench_srs(d + 1)
+    eng = K.Engine(devices=[0, 0, 0])
+    try:
+        eng.srs_generate(secret, d + 1)
+        eng.set_max_batch(3)
+        rnd = random.Random(77)
+        polys = [c] + [K.scalars_to_limbs([rnd.randrange(K.R_MODULUS) for _ in range(d + 1)]) for _ in range(4)]
+        zs = [z] + [K.Scalar(rnd.randrange(K.R_MODULUS)) for _ in range(4)]
+        ys = [y] + [single.evaluate_limbs(p, zz) for p, zz in zip(polys[1:], zs[1:])]
+        commits = eng.commit_batch_host(polys)
+        assert commits[0].compress().hex() == case["commit"]
+        for k in range(1, 5):
+            assert commits[k].compress() == single.commit_limbs(polys[k]).compress()
+        ys_bad = list(ys)
+        ys_bad[2] = K.Scalar((ys[2].v + 1) % K.R_MODULUS)
+        proofs = eng.open_batch_host(polys, zs, ys_bad)
+        assert proofs[0].compress().hex() == case["proof"]
+        assert isinstance(proofs[2], K.KzgError) and proofs[2].status == K.KZG_ERR_REMAINDER
+        for k in (1, 3, 4):
+            assert proofs[k].compress() == single.open_limbs(polys[k], zs[k], ys[k]).compress()
+    finally:
+        eng.close()
+
+
+def test_host_pointer_batches_on_one_device(engines, oracle, golden):
+    """kzg_commit_batch / kzg_open_batch on a single-device context: sub-batches pipelined through the stream slots
+    (11 polynomials, at most 3 per pass), same bytes as one call per polynomial; constant and empty polynomials take
+    the single-opening rules."""
+    secret = bytes.fromhex(golden["secret_be"])
+    d = 1000
+    eng = K.SetupArtifactsGenerator(secret).take(d + 1)
+    single = engines.bench_srs(d + 1)
+    try:
+        assert eng.set_max_batch(3) == 3
+        rnd = random.Random(11)
+        polys = [K.scalars_to_limbs([K.Scalar.from_i128(rnd.randrange(-(1 << 127), 1 << 127)).v for _ in range(d + 1)])
+                 for _ in range(11)]
+        zs = [K.Scalar(rnd.randrange(K.R_MODULUS)) for _ in polys]
+        ys = [single.evaluate_limbs(p, zz) for p, zz in zip(polys, zs)]
+        commits = eng.commit_batch_host(polys)
+        proofs = eng.open_batch_host(polys, zs, ys)
+        for k in range(11):
+            assert commits[k].compress() == single.commit_limbs(polys[k]).compress(), k
+            assert proofs[k].compress() == single.open_limbs(polys[k], zs[k], ys[k]).compress(), k
+        assert eng.commit_batch_host(polys[:1])[0].compress() == commits[0].compress()
+        # constant polynomials (n == 1): c0 == y -> infinity, otherwise the reference's error, per polynomial
+        consts = [K.scalars_to_limbs([5]), K.scalars_to_limbs([6])]
+        res = eng.open_batch_host(consts, [zs[0], zs[1]], [K.Scalar(5), K.Scalar(5)])
+        assert res[0].is_infinity() and isinstance(res[1], K.KzgError) and res[1].status == K.KZG_ERR_CONSTANT_POLY
+        with pytest.raises(K.KzgError) as ei:  # batches take truncated polynomials only
+            eng.commit_batch_host([np.concatenate([polys[0], np.zeros((1, 4), dtype=np.uint64)])])
+        assert ei.value.status == K.KZG_ERR_DEGREE_TOO_HIGH
+    finally:
+        eng.close()
+
+
+def test_replicated_context_splits_batches_by_polynomial(engines, oracle, twin, golden):
+    """SURVEY section 8(e), config 5's partition in miniature: 8 devices with the WHOLE SRS each (virtual devices on a
+    one-GPU box), 64 openings in ONE kzg_open_batch call -- polynomial p on device p mod 8, nothing exchanged --
+    verified one by one with the pairing check like src/lib.rs:16-33; single calls take the devices in turn."""
+    import pairing_twin as PT
+
+    rnd = random.Random(640)
+    secret = bytes(rnd.randrange(256) for _ in range(32))
+    s = int.from_bytes(secret, "big") % K.R_MODULUS
+    n = 1025
+    eng = K.Engine(devices=_eight_devices(), replicate=True)
+    try:
+        eng.srs_generate(secret, n)
+        assert eng.num_devices() == 8 and eng.srs_len() == n
+        assert eng.set_max_batch(4) == 4
+        polys = [K.scalars_to_limbs([K.Scalar.from_i128(rnd.randrange(-(1 << 127), 1 << 127)).v for _ in range(n)])
+                 for _ in range(64)]
+        zs = [K.Scalar.from_i128(rnd.randrange(-(1 << 127), 1 << 127)) for _ in polys]
+        ys = [eng.evaluate_limbs(p, z) for p, z in zip(polys, zs)]
+        commitments = eng.commit_batch_host(polys)
+        ys_claimed = list(ys)
+        ys_claimed[41] = K.Scalar((ys[41].v + 1) % K.R_MODULUS)
+        proofs = eng.open_batch_host(polys, zs, ys_claimed)
+        assert isinstance(proofs[41], K.KzgError) and proofs[41].status == K.KZG_ERR_REMAINDER
+        proofs[41] = eng.open_limbs(polys[41], zs[41], ys[41])
+        (xa, xb), (ya, yb) = PT.g2_mul(PT.G2, s)
+        mont = lambda v: [((v << 384) % twin.P >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]  # noqa: E731
+        s_g2 = mont(xa) + mont(xb) + mont(ya) + mont(yb) + mont(1) + mont(0)
+        assert K.verify_proof_batch(commitments, proofs, zs, ys, s_g2) == [True] * 64
+        # same bytes as a single-device engine on the same SRS
+        one = K.SetupArtifactsGenerator(secret).take(n)
+        try:
+            for k in (0, 7, 8, 63):
+                assert commitments[k].compress() == one.commit_limbs(polys[k]).compress()
+                assert proofs[k].compress() == one.open_limbs(polys[k], zs[k], ys[k]).compress()
+        finally:
+            one.close()
+        assert eng.rccl_exchanges() == 0
+    finally:
+        eng.close()
+
+
+def test_config5_sixteen_degree_2_20_openings_over_eight_devices(oracle, twin, golden):
+    """BASELINE config 5's shape at full degree through the by-polynomial path: 16 degree-2^20 openings (64 when the
+    8-GPU node is visible) in one kzg_open_batch on a replicated-SRS context of 8 devices, then kzg_verify_proof_batch.
+    The opening at the reference bench's point must equal the golden proof."""
+    import pairing_twin as PT
+    import torch
+
+    d = 1 << 20
+    n = d + 1
+    case = _case(golden, d)
+    secret = bytes.fromhex(golden["secret_be"])
+    s = int.from_bytes(secret, "big") % K.R_MODULUS
+    c, z0, y0 = _bench_poly(oracle, d)
+    batch = 64 if torch.cuda.device_count() >= 8 else 16
+    eng = K.Engine(devices=_eight_devices(), replicate=True)
+    try:
+        eng.srs_generate(secret, n)
+        assert eng.set_max_batch(2) == 2
+        r = K.R_MODULUS
+        zs = [z0] + [K.Scalar((z0.v * (k + 2) + 12345 * k) % r) for k in range(1, batch)]
+        ys = [eng.evaluate_limbs(c, z) for z in zs]
+        assert ys[0] == y0
+        flat = np.broadcast_to(np.ascontiguousarray(c, dtype=np.uint64).reshape(1, n, 4), (batch, n, 4))
+        proofs = eng.open_batch_host(np.ascontiguousarray(flat), zs, ys)
+        assert not any(isinstance(p, K.KzgError) for p in proofs)
+        assert proofs[0].compress().hex() == case["proof"]
+        assert len({p.compress() for p in proofs}) == batch
+        commitment = K.G1Point.uncompress(bytes.fromhex(case["commit"]))
+        (xa, xb), (ya, yb) = PT.g2_mul(PT.G2, s)
+        mont = lambda v: [((v << 384) % twin.P >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]  # noqa: E731
+        s_g2 = mont(xa) + mont(xb) + mont(ya) + mont(yb) + mont(1) + mont(0)
+        assert K.verify_proof_batch([commitment] * batch, proofs, zs, ys, s_g2) == [True] * batch
     finally:
         eng.close()
 
