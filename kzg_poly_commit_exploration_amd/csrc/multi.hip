@@ -34,6 +34,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -148,7 +150,16 @@ struct MultiState {
     uint64_t* h_stage = nullptr;         // pinned: K x kExchangeMaxPartials x 18 words up, the same down
     std::string last_error;
     std::atomic<uint64_t> rccl_exchanges{0};
+    // KZG_HOST_TRACE=1: per sharded call, wall time of the call, of its slowest device thread and of the exchange + sum
+    // (printed when the context is destroyed): call - slowest device = what the context adds on top of its shards
+    bool trace = false, trace_in_call = false;
+    uint64_t trace_calls = 0, trace_call_ns = 0, trace_slowest_ns = 0, trace_exchange_ns = 0;
+    std::vector<uint64_t> kid_ns;  // per device, current round
 };
+
+static uint64_t now_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static void shard_range(size_t n, size_t g, size_t k, size_t& lo, size_t& hi) {
     const size_t per = (n + k - 1) / k;
@@ -198,6 +209,8 @@ int multi_create(const int* devices, int ndev, uint32_t mode, MultiState** out, 
     m->lo.assign(ndev, 0);
     m->hi.assign(ndev, 0);
     m->pool = new WorkerPool(m->devices);
+    m->kid_ns.assign(ndev, 0);
+    if (const char* v = std::getenv("KZG_HOST_TRACE")) m->trace = std::atoi(v) != 0;
     // The exchange of a range-split context goes over RCCL when a communicator can be formed: it needs distinct
     // devices (KZG_MULTI_FORCE_RCCL=1 forms one for a single device too -- a world of one, which is how the GPU suite
     // exercises the exchange code on a one-GPU box).  KZG_MULTI_EXCHANGE=host never forms one.
@@ -241,6 +254,13 @@ int multi_create(const int* devices, int ndev, uint32_t mode, MultiState** out, 
 
 void multi_destroy(MultiState* m) {
     if (!m) return;
+    if (m->trace && m->trace_calls) {
+        const double k = 1e-3 / (double)m->trace_calls;
+        std::fprintf(stderr, "[kzg multi trace] %llu sharded calls on %zu devices, us per call: total %.1f slowest device of every round %.1f exchange+sum %.1f "
+                             "=> context overhead %.1f\n",
+                     (unsigned long long)m->trace_calls, m->kids.size(), k * m->trace_call_ns, k * m->trace_slowest_ns,
+                     k * m->trace_exchange_ns, k * (m->trace_call_ns - m->trace_slowest_ns));
+    }
     delete m->pool;
     release_exchange(m);
     for (auto* k : m->kids) kzg_ctx_destroy(k);
@@ -256,7 +276,15 @@ uint32_t multi_mode(const MultiState* m) { return m->mode; }
 
 // fn(g) on every device, each on its own persistent host thread; returns the first non-OK status in device order
 static int for_each_kid(MultiState* m, const std::function<int(size_t)>& fn) {
-    const std::vector<int>& rc = m->pool->run(fn);
+    const std::function<int(size_t)> traced = [&](size_t g) {
+        const uint64_t t0 = now_ns();
+        const int r = fn(g);
+        m->kid_ns[g] += now_ns() - t0;
+        return r;
+    };
+    if (m->trace) std::fill(m->kid_ns.begin(), m->kid_ns.end(), 0);
+    const std::vector<int>& rc = m->pool->run(m->trace ? traced : fn);
+    if (m->trace && m->trace_in_call) m->trace_slowest_ns += *std::max_element(m->kid_ns.begin(), m->kid_ns.end());  // per round over the devices
     for (size_t g = 0; g < rc.size(); g++)
         if (rc[g] != KZG_OK) {
             m->last_error = std::string("device slice ") + std::to_string(g) + ": " + kzg_last_error(m->kids[g]);
@@ -356,7 +384,14 @@ int multi_set_max_batch(MultiState* m, size_t max_batch) {
 
 // The exchange and the sum.  partials: device-major [g][b], b < count, 18 words each (un-normalised Jacobian, all-zero
 // Z = infinity); out: count normalised blst_p1.  Over RCCL when the context owns a communicator.
+static int exchange_and_sum_impl(MultiState* m, const uint64_t* partials, size_t count, uint64_t* out_p1s);
 static int exchange_and_sum(MultiState* m, const uint64_t* partials, size_t count, uint64_t* out_p1s) {
+    const uint64_t t0 = m->trace ? now_ns() : 0;
+    const int rc = exchange_and_sum_impl(m, partials, count, out_p1s);
+    if (m->trace) m->trace_exchange_ns += now_ns() - t0;
+    return rc;
+}
+static int exchange_and_sum_impl(MultiState* m, const uint64_t* partials, size_t count, uint64_t* out_p1s) {
     const size_t k = m->kids.size();
     std::vector<hf::P1> sums(count);
     if (!m->rccl) {
@@ -434,6 +469,18 @@ static int exchange_and_sum(MultiState* m, const uint64_t* partials, size_t coun
     return KZG_OK;
 }
 
+struct CallTrace {  // one sharded call: started after op_mu is taken
+    MultiState* m;
+    uint64_t t0;
+    explicit CallTrace(MultiState* ms) : m(ms), t0(ms->trace ? now_ns() : 0) { m->trace_in_call = true; }
+    ~CallTrace() {
+        m->trace_in_call = false;
+        if (!m->trace) return;
+        m->trace_calls++;
+        m->trace_call_ns += now_ns() - t0;
+    }
+};
+
 static bool fr_words_nonzero(const uint64_t* c, size_t from, size_t to) {
     for (size_t i = from; i < to; i++)
         if (c[4 * i] | c[4 * i + 1] | c[4 * i + 2] | c[4 * i + 3]) return true;
@@ -448,6 +495,7 @@ int multi_commit(MultiState* m, const void* scalars, int is_mont, size_t n, uint
         return is_mont ? kzg_commit(kid, (const uint64_t*)scalars, n, out_p1) : kzg_commit_le_bytes(kid, (const uint8_t*)scalars, n, out_p1);
     }
     std::lock_guard<std::mutex> lk(m->op_mu);
+    CallTrace trace(m);
     m->last_error.clear();
     // coefficients beyond the SRS make the degree too high only when one of them is non-zero
     // (src/polynomial.rs:55-75, 201-205): same rule as the single-device context
@@ -472,6 +520,7 @@ int multi_open(MultiState* m, const uint64_t* coeffs, size_t n, const uint64_t z
     const size_t k = m->kids.size();
     if (m->mode == kMultiReplicate) return kzg_open(m->kids[m->next_kid.fetch_add(1) % k], coeffs, n, z, y, out_p1);
     std::lock_guard<std::mutex> lk(m->op_mu);
+    CallTrace trace(m);
     m->last_error.clear();
     std::memset(out_p1, 0, 144);
     hf::Fr zf, yf;
