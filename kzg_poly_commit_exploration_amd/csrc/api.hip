@@ -598,6 +598,10 @@ int kzg_ctx_create(int device, kzg_ctx** out) {
         ctx->small_lds_bytes = small_msm_lds_bytes();
     else
         (void)hipGetLastError();  // stays at 48 KiB: two workgroups may then share a CU (slower, not wrong)
+    if (!poly_prepare_device()) {
+        delete ctx;
+        return KZG_ERR_HIP;  // the quotient kernels could not be launched on this device
+    }
     if (ctx->gate_lds_bytes > 64u * 1024u) {
         // more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
         if (hipFuncSetAttribute((const void*)k_reduce_gate, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1009,12 +1013,11 @@ static int submit_open_locked(kzg_ctx* ctx, int slot, const uint32_t* d_coeffs, 
     uint32_t zw[8];
     std::memcpy(zw, z, 32);
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[6], s.stream));
-    // small polynomials: one launch for the scan, the flag words and c0; otherwise memset + three launches + a copy
+    // small polynomials: one launch for the scan, the flag words and c0; otherwise memset + two launches (c0 written by the first)
     if (!launch_quotient_single(s.stream, d_coeffs, (uint32_t)n, zw, n > 1 ? s.d_q : nullptr, s.d_small)) {
         HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
         PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
         launch_quotient(s.stream, d_coeffs, (uint32_t)n, zw, n > 1 ? s.d_q : nullptr, sc);
-        HIP_TRY(ctx, hipMemcpyAsync(s.d_small + 16, d_coeffs, 32, hipMemcpyDeviceToDevice, s.stream));  // c0
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[7], s.stream));
     size_t nq = n - 1;
@@ -1245,7 +1248,6 @@ static int open_batch_submit_locked(kzg_ctx* ctx, int slot, const void* d_coeffs
         uint32_t* sm = s.d_bsmall + p * 32;
         PolyScratch sc{s.d_chunk, s.d_block, sm, sm + 8};  // scratch re-used in stream order
         launch_quotient(s.stream, cp, (uint32_t)n, zw, s.d_q + p * nq * 8, sc);
-        HIP_TRY(ctx, hipMemcpyAsync(sm + 16, cp, 32, hipMemcpyDeviceToDevice, s.stream));  // c0
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[7], s.stream));
     rc = enqueue_msm(ctx, s, s.d_q, 1, nq, 0, (uint32_t)batch, nq);

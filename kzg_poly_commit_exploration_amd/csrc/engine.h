@@ -198,9 +198,11 @@ uint32_t multi_mode(const MultiState* m);
 struct PolyScratch {
     uint32_t* d_chunk;   // per-thread chunk values / carries (Fr)
     uint32_t* d_block;   // per-block aggregates (Fr)
-    uint32_t* d_flags;   // [0] = any non-zero coefficient with index >= 1
+    uint32_t* d_flags;   // the job's flag words, zero at launch: [0] = any non-zero coefficient with index >= 1, [16..23] receive c[0]
     uint32_t* d_result;  // P(z) (8 words)
 };
+// raises the dynamic-LDS limit of the scan kernels on the current device (kzg_ctx_create); false when refused
+bool poly_prepare_device();
 size_t poly_chunk_words(uint32_t n);
 size_t poly_block_words(uint32_t n);
 // suffix Horner scan S[i] = sum_{k>=i} c[k] z^(k-i):  q[i-1] = S[i] (i >= 1) when d_q != nullptr,

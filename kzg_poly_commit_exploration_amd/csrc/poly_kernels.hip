@@ -7,17 +7,28 @@
 // and its final check  -z q[0] == c[0] - y  is  P(z) == y.  Subtracting y only changes c[0], which
 // no S[i >= 1] reads, so the same scan serves Polynomial::evaluate (src/polynomial.rs:112-123).
 //
-// Three launches over chunks of L coefficients per lane (coefficients past n count as zero):
-//   1. chunk Horner values, then a Kogge-Stone suffix scan inside the workgroup (multipliers
-//      z^(L 2^s), one Fr product per step), workgroup aggregates out;
-//   2. one workgroup scans the aggregates (multiplier z^(L*256); each lane takes a run of blocks);
-//   3. every lane replays its chunk from its now-known carry and writes q.
+// Two launches over chunks of L coefficients per lane (coefficients past n count as zero):
+//   1. k_poly_chunks: chunk Horner values, a Kogge-Stone suffix scan inside the workgroup (multipliers z^(L 2^s), one
+//      Fr product per step), workgroup aggregates A_u out;
+//   2. k_poly_apply: every workgroup derives its own carry from the aggregates above it,
+//      C_b = sum_{u > b} A_u zb^(u-b-1) with zb = z^(L*256): each lane takes the blocks b+1+t, b+1+t+256, ... (two
+//      products per term, the powers from a 16 + 16 entry table), an addition tree over the lanes sums them -- no
+//      workgroup waits for another and no third launch sits between the two; then every lane replays its chunk from
+//      its now-known carry and writes q.  Workgroup 0 also leaves P(z) = A_0 + zb C_0.
+//      (A version that let the last workgroup of launch 1 scan the aggregates behind an arrival counter measured 114 us
+//      for that launch against 55: 512 agent-scope releases, each a write-back + invalidate of an XCD's L2.  Beyond 1024
+//      blocks -- 2^21 coefficients -- a one-workgroup scan of the aggregates runs as a launch of its own.)
+// Memory: a lane owns L CONSECUTIVE coefficients (the recurrence is sequential in the index), which read directly is a
+// 256-byte lane stride: every wave-level load touches 64 lines for 16 bytes each, and the Horner loop waits for each
+// one in turn (round 2: 52 + 22 + 35 us at 2^20, 2.4 x the algorithmic bytes at the memory controller).  Both kernels
+// therefore move their tile through LDS: consecutive lanes load consecutive 16-byte words (all 16 loads of a lane in
+// flight at once), the wave's 16 KiB land in LDS with one pad word per lane chunk (conflict-free both ways), each lane
+// reads its own chunk from there; the quotient goes out the same way in reverse.
 // Every power of z a lane needs (z^8 and its repeated squares for the scan inside a workgroup, z^2048 and the
 // powers of the block stage, the 2 x 16 entry table of the replay) is computed ONCE on the host (~60 Fr products,
-// host_fr.hpp) and travels as a kernel argument: the per-lane chains of dependent Fr products drop from 28 / 31 / 22
-// to 16 / 12 / 10 in the three kernels, which is what these latency-bound launches cost.
-// Algorithmic bytes: 32 B read + 32 B written per coefficient; the chunk
-// is read twice (the second time mostly from L2 / Infinity Cache).  HBM / latency bound.
+// host_fr.hpp) and travels as a kernel argument.
+// Algorithmic bytes: 32 B read + 32 B written per coefficient; the coefficients are read
+// twice (96 B per coefficient at the memory controller).  HBM / latency bound.
 #include "engine.h"
 #include "field.hip.h"
 #include "host_fr.hpp"
@@ -62,7 +73,10 @@ struct PolyPowers {
     FrArg z;
     FrArg zl_sq[8];    // (z^L)^(2^s): multipliers of the scan inside a workgroup
     FrArg zb;          // z^(L * 256): one workgroup up
-    FrArg zbp_sq[8];   // (zb^per)^(2^s): multipliers of the scan over the lanes of the block stage
+    FrArg zbp_sq[8];   // (zb^per)^(2^s): multipliers of the scan over the lanes of the block stage (more than kPolyDirectBlocks blocks)
+    FrArg ba[16];      // zb^(16 e)
+    FrArg bb[16];      // zb^e
+    FrArg zb256;       // zb^256
     FrArg pa[16];      // (z^L)^(16 e)
     FrArg pb[16];      // (z^L)^e
 };
@@ -87,44 +101,57 @@ KZG_DEV Fr block_suffix_scan(Fr v, const FrArg* mults /* mult^(2^s), s < log2(BL
     return v;
 }
 
-__global__ void __launch_bounds__(kPolyBlock) k_poly_chunks(const uint32_t* __restrict__ coeffs, uint32_t n, PolyPowers pw,
-                                                            uint32_t* __restrict__ d_chunk,
-                                                            uint32_t* __restrict__ d_block,
-                                                            uint32_t* __restrict__ d_flags) {
-    __shared__ uint32_t lds[kPolyBlock * 8];
-    const Fr z = fr_from_arg(pw.z);
-    const uint32_t t = blockIdx.x * kPolyBlock + threadIdx.x;
-    const uint32_t base = t * kPolyL;
-    Fr h = Fr::zero();
-    bool nz = false;
-#pragma unroll 1
-    for (int k = kPolyL - 1; k >= 0; k--) {
-        uint32_t idx = base + k;
-        h = fe_mul(h, z);
-        if (idx < n) {
-            Fr c = load_fr(coeffs + (size_t)idx * 8);
-            if (idx >= 1 && !c.is_zero()) nz = true;
-            h = fe_add(h, c);
-        }
+// ---- tile staging through LDS -------------------------------------------------------------------------------------
+// A wave owns 64 x kPolyL coefficients = 64 x 16 uint4.  Global side: word g = i * 64 + lane (i < 16), consecutive lanes
+// on consecutive 16-byte words.  LDS side: word g sits at g + g / 16 (one pad word behind every lane chunk of 16), so the
+// row-wise writes are contiguous runs of 16 and the chunk-wise reads of lane l (words 17 l + j) fall on different banks
+// for 16 consecutive lanes.  Only the lanes of one wave touch one region: wave-level ordering is enough.
+constexpr int kPolyWaveWords = 64 * 2 * kPolyL;                         // uint4 per wave (1024)
+constexpr int kPolyWaveLds = kPolyWaveWords + kPolyWaveWords / 16;      // padded (1088)
+static_assert(kPolyL == 8, "the staging below is laid out for 16 uint4 per lane");
+KZG_DEV uint32_t poly_lds_slot(uint32_t g) { return g + (g >> 4); }
+KZG_DEV void poly_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// coefficients [first, first + 512) of `coeffs` (zero past n) -> the wave's LDS region
+KZG_DEV void poly_stage_in(const uint32_t* __restrict__ coeffs, uint64_t first, uint32_t n, uint4* __restrict__ lds_wave, uint32_t lane) {
+    const uint4* src = reinterpret_cast<const uint4*>(coeffs) + 2 * first;
+    const uint64_t valid = first < n ? 2 * ((uint64_t)n - first) : 0;  // uint4 words of the region that exist
+    // every load is issued unconditionally (words past the end read coefficient 0 instead and are zeroed afterwards): a
+    // guarded load becomes a branch with a wait behind it, and the 16 loads of a lane must be in flight together
+    uint4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = (uint32_t)i * 64u + lane;
+        const uint4* p = g < valid ? src + g : reinterpret_cast<const uint4*>(coeffs);
+        v[i] = *p;
     }
-    if (__any(nz) && (threadIdx.x & 63) == 0) atomicOr(&d_flags[0], 1u);
-    h = block_suffix_scan<kPolyBlock>(h, pw.zl_sq, lds);
-    store_fr(d_chunk + (size_t)t * 8, h);
-    if (threadIdx.x == 0) store_fr(d_block + (size_t)blockIdx.x * 8, h);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = (uint32_t)i * 64u + lane;
+        lds_wave[poly_lds_slot(g)] = g < valid ? v[i] : make_uint4(0, 0, 0, 0);
+    }
+    poly_wave_sync();
+}
+KZG_DEV Fr poly_lds_coeff(const uint4* __restrict__ lds_wave, uint32_t lane, int k) {
+    const uint4 lo = lds_wave[17u * lane + 2u * (uint32_t)k], hi = lds_wave[17u * lane + 2u * (uint32_t)k + 1u];
+    Fr a;
+    a.l[0] = lo.x; a.l[1] = lo.y; a.l[2] = lo.z; a.l[3] = lo.w;
+    a.l[4] = hi.x; a.l[5] = hi.y; a.l[6] = hi.z; a.l[7] = hi.w;
+    return a;
 }
 
-// single workgroup: carries for every block.  d_block[b] in: aggregate of block b (zero carry-in);
+// single workgroup's worth of work: carries for every block.  d_block[b] in: aggregate of block b (zero carry-in);
 // out: d_block[b] = S at the first coefficient of block b+1 (its carry-in); d_result = P(z).
-// 256 lanes (one wave per SIMD, 86 VGPRs): small enough to start beside two resident accumulation waves of
-// another slot -- the former 1024-lane version needed 4 x 86 VGPRs per SIMD and waited ~1 ms for them.
 // Lane t owns `per` consecutive blocks: Horner over its blocks, Kogge-Stone across lanes, replay.
-__global__ void __launch_bounds__(kPolyBlock) k_poly_blocks(uint32_t* __restrict__ d_block, uint32_t nblocks, PolyPowers pw,
-                                                            uint32_t* __restrict__ d_result) {
-    __shared__ uint32_t lds[kPolyBlock * 8];
+KZG_DEV void poly_block_stage(uint32_t* __restrict__ d_block, uint32_t nblocks, const PolyPowers& pw, uint32_t* __restrict__ d_result,
+                              uint32_t* lds) {
     const Fr zb = fr_from_arg(pw.zb);  // one block up
     const uint32_t t = threadIdx.x;
     const uint32_t per = (nblocks + kPolyBlock - 1) / kPolyBlock;
-    const uint32_t lo = t * per;
+    const uint32_t lo = t * per < nblocks ? t * per : nblocks;
     const uint32_t hi = lo + per < nblocks ? lo + per : nblocks;
     Fr h = Fr::zero();
     for (uint32_t u = hi; u-- > lo;) h = fe_add(fe_mul(h, zb), load_fr(d_block + (size_t)u * 8));
@@ -147,15 +174,102 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_blocks(uint32_t* __restrict
     if (t == 0) store_fr(d_result, s);  // S[0] = P(z)
 }
 
+// d_flags: the job's flag words -- [0] |= any non-zero coefficient with index >= 1, [16..23] receive c[0] (what the
+// constant-polynomial rule compares with y, src/polynomial.rs:159-167).
+__global__ void __launch_bounds__(kPolyBlock) k_poly_chunks(const uint32_t* __restrict__ coeffs, uint32_t n, PolyPowers pw,
+                                                            uint32_t* __restrict__ d_chunk,
+                                                            uint32_t* __restrict__ d_block,
+                                                            uint32_t* __restrict__ d_flags) {
+    extern __shared__ uint4 lds_tile[];                       // 4 waves x kPolyWaveLds uint4
+    __shared__ uint32_t lds[kPolyBlock * 8];
+    const Fr z = fr_from_arg(pw.z);
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint4* lds_wave = lds_tile + wave * kPolyWaveLds;
+    const uint32_t t = blockIdx.x * kPolyBlock + threadIdx.x;
+    const uint64_t wave_first = ((uint64_t)blockIdx.x * kPolyBlock + wave * 64u) * kPolyL;
+    poly_stage_in(coeffs, wave_first, n, lds_wave, lane);
+    Fr h = Fr::zero();
+    bool nz = false;
+#pragma unroll
+    for (int k = kPolyL - 1; k >= 0; k--) {
+        const Fr c = poly_lds_coeff(lds_wave, lane, k);
+        if (((uint64_t)t * kPolyL + k) >= 1 && !c.is_zero()) nz = true;  // (coefficients past n were staged as zero)
+        h = fe_add(fe_mul(h, z), c);
+    }
+    if (__any(nz) && lane == 0) atomicOr(&d_flags[0], 1u);
+    if (t == 0) store_fr(d_flags + 16, poly_lds_coeff(lds_wave, 0, 0));  // c[0]
+    h = block_suffix_scan<kPolyBlock>(h, pw.zl_sq, lds);
+    store_fr(d_chunk + (size_t)t * 8, h);
+    if (threadIdx.x == 0) store_fr(d_block + (size_t)blockIdx.x * 8, h);
+}
+
+__global__ void __launch_bounds__(kPolyBlock) k_poly_blocks(uint32_t* __restrict__ d_block, uint32_t nblocks, PolyPowers pw,
+                                                            uint32_t* __restrict__ d_result) {
+    __shared__ uint32_t lds[kPolyBlock * 8];
+    poly_block_stage(d_block, nblocks, pw, d_result, lds);
+}
+
+// C_b = sum_{u > b} A_u zb^(u-b-1) for this workgroup's block b (b = -1: everything, i.e. P(z)): terms spread over the
+// lanes, summed by an addition tree through LDS; every lane returns the sum
+constexpr uint32_t kPolyDirectBlocks = 1024;  // beyond: k_poly_blocks prepares the carries
+KZG_DEV Fr poly_carry_from_aggregates(const uint32_t* __restrict__ d_block, uint32_t nblocks, uint32_t first /* b + 1 */,
+                                      const PolyPowers& pw, uint32_t* lds /* kPolyBlock * 8 words */) {
+    const uint32_t t = threadIdx.x;
+    Fr sum = Fr::zero();
+    if (first + t < nblocks) {
+        Fr power = fe_mul(fr_from_arg(pw.ba[t >> 4]), fr_from_arg(pw.bb[t & 15]));  // zb^t
+        const Fr stride = fr_from_arg(pw.zb256);
+        for (uint32_t u = first + t; u < nblocks; u += kPolyBlock) {
+            sum = fe_add(sum, fe_mul(load_fr(d_block + (size_t)u * 8), power));
+            if (u + kPolyBlock < nblocks) power = fe_mul(power, stride);
+        }
+    }
+    for (int off = kPolyBlock / 2; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) lds[i * kPolyBlock + t] = sum.l[i];
+        __syncthreads();
+        if ((int)t < off) {
+            Fr o;
+#pragma unroll
+            for (int i = 0; i < 8; i++) o.l[i] = lds[i * kPolyBlock + t + off];
+            sum = fe_add(sum, o);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) lds[i * kPolyBlock + t] = sum.l[i];
+    __syncthreads();
+    Fr total;
+#pragma unroll
+    for (int i = 0; i < 8; i++) total.l[i] = lds[i * kPolyBlock];
+    return total;
+}
+
+// direct != 0: d_block holds the aggregates A_u (carries are derived here, workgroup 0 writes P(z) to d_result);
+// direct == 0: d_block holds the carries (k_poly_blocks ran).  d_q == nullptr: only P(z) is wanted (one workgroup).
 __global__ void __launch_bounds__(kPolyBlock) k_poly_apply(const uint32_t* __restrict__ coeffs, uint32_t n, PolyPowers pw,
                                                            const uint32_t* __restrict__ d_chunk,
-                                                           const uint32_t* __restrict__ d_block,
-                                                           uint32_t* __restrict__ d_q) {
+                                                           const uint32_t* __restrict__ d_block, uint32_t nblocks, int direct,
+                                                           uint32_t* __restrict__ d_q, uint32_t* __restrict__ d_result) {
+    extern __shared__ uint4 lds_tile[];
+    __shared__ uint32_t lds[kPolyBlock * 8];
     const Fr z = fr_from_arg(pw.z);
     const int tl = threadIdx.x;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint4* lds_wave = lds_tile + wave * kPolyWaveLds;
     const uint32_t t = blockIdx.x * kPolyBlock + tl;
-    // carry into this lane's chunk = S at the first coefficient of the next chunk
-    Fr blk_carry = load_fr(d_block + (size_t)blockIdx.x * 8);
+    const uint64_t wave_first = ((uint64_t)blockIdx.x * kPolyBlock + wave * 64u) * kPolyL;
+    if (d_q) poly_stage_in(coeffs, wave_first, n, lds_wave, lane);  // in flight while the carry is worked out
+    // carry into this workgroup's block = S at the first coefficient of the next block
+    Fr blk_carry;
+    if (direct) {
+        blk_carry = poly_carry_from_aggregates(d_block, nblocks, blockIdx.x + 1, pw, lds);
+        if (blockIdx.x == 0 && tl == 0)  // P(z) = S[0] = A_0 + zb C_0
+            store_fr(d_result, fe_add(load_fr(d_block), fe_mul(fr_from_arg(pw.zb), blk_carry)));
+    } else {
+        blk_carry = load_fr(d_block + (size_t)blockIdx.x * 8);
+    }
+    if (!d_q) return;
     Fr h;
     uint32_t dist = (uint32_t)(kPolyBlock - 1 - tl);  // chunks between the next chunk and the block end
     const Fr pa = fr_from_arg(pw.pa[dist >> 4]), pb = fr_from_arg(pw.pb[dist & 15]);  // (z^L)^dist = pa * pb
@@ -165,15 +279,21 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_apply(const uint32_t* __res
     } else {
         h = scaled;  // dist == 0: the block carry itself
     }
-    const uint32_t base = t * kPolyL;
-#pragma unroll 1
+    // replay: S at every coefficient of the chunk, written back into the lane's own LDS words
+#pragma unroll
     for (int k = kPolyL - 1; k >= 0; k--) {
-        uint32_t idx = base + k;
-        h = fe_mul(h, z);
-        if (idx < n) {
-            h = fe_add(h, load_fr(coeffs + (size_t)idx * 8));
-            if (idx >= 1) store_fr(d_q + (size_t)(idx - 1) * 8, h);
-        }
+        h = fe_add(fe_mul(h, z), poly_lds_coeff(lds_wave, lane, k));
+        lds_wave[17u * lane + 2u * (uint32_t)k] = make_uint4(h.l[0], h.l[1], h.l[2], h.l[3]);
+        lds_wave[17u * lane + 2u * (uint32_t)k + 1u] = make_uint4(h.l[4], h.l[5], h.l[6], h.l[7]);
+    }
+    poly_wave_sync();
+    // q[i - 1] = S[i]: the wave's 512 values go out one coefficient lower, consecutive lanes on consecutive words
+    uint4* dst = reinterpret_cast<uint4*>(d_q) + 2 * wave_first;  // word g of the region belongs at dst[g - 2]
+    const uint64_t valid = wave_first < n ? 2 * ((uint64_t)n - wave_first) : 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t g = (uint32_t)i * 64u + lane;
+        if (g < valid && (wave_first != 0 || g >= 2)) dst[(int64_t)g - 2] = lds_wave[poly_lds_slot(g)];
     }
 }
 
@@ -231,6 +351,15 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_single(const uint32_t* __re
     }
 }
 
+// the scan kernels stage a tile of 68 KiB: more than the 64 KiB a workgroup gets by default (once per device)
+constexpr uint32_t kPolyTileLds = (kPolyBlock / 64) * kPolyWaveLds * 16;
+bool poly_prepare_device() {
+    const bool a = hipFuncSetAttribute((const void*)k_poly_chunks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPolyTileLds) == hipSuccess;
+    const bool b = hipFuncSetAttribute((const void*)k_poly_apply, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPolyTileLds) == hipSuccess;
+    if (!(a && b)) (void)hipGetLastError();
+    return a && b;
+}
+
 bool launch_quotient_single(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const uint32_t z_mont[8], uint32_t* d_q,
                             uint32_t* d_small) {
     if (n == 0 || n > kPolySingleMax) return false;
@@ -279,10 +408,22 @@ void launch_quotient(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const 
         a = hf::fr_mul(a, zl16);
         b = hf::fr_mul(b, zl);
     }
-    hipLaunchKernelGGL(k_poly_chunks, dim3(nblocks), dim3(kPolyBlock), 0, s, d_coeffs, n, pw, sc.d_chunk, sc.d_block, sc.d_flags);
-    hipLaunchKernelGGL(k_poly_blocks, dim3(1), dim3(kPolyBlock), 0, s, sc.d_block, nblocks, pw, sc.d_result);
-    if (d_q && n > 1)
-        hipLaunchKernelGGL(k_poly_apply, dim3(nblocks), dim3(kPolyBlock), 0, s, d_coeffs, n, pw, sc.d_chunk, sc.d_block, d_q);
+    hf::Fr m16 = hf::fr_pow(m, 16), ba = hf::kFrOne, bb = hf::kFrOne;
+    for (int e = 0; e < 16; e++) {
+        put(pw.ba[e], ba);
+        put(pw.bb[e], bb);
+        ba = hf::fr_mul(ba, m16);
+        bb = hf::fr_mul(bb, m);
+    }
+    put(pw.zb256, ba);  // (zb^16)^16
+    constexpr uint32_t tile_lds = kPolyTileLds;
+    hipLaunchKernelGGL(k_poly_chunks, dim3(nblocks), dim3(kPolyBlock), tile_lds, s, d_coeffs, n, pw, sc.d_chunk, sc.d_block, sc.d_flags);
+    const int direct = nblocks <= kPolyDirectBlocks;
+    if (!direct) hipLaunchKernelGGL(k_poly_blocks, dim3(1), dim3(kPolyBlock), 0, s, sc.d_block, nblocks, pw, sc.d_result);
+    uint32_t* q = (d_q && n > 1) ? d_q : nullptr;
+    if (q || direct)  // (without a quotient: one workgroup that leaves P(z))
+        hipLaunchKernelGGL(k_poly_apply, dim3(q ? nblocks : 1), dim3(kPolyBlock), q ? tile_lds : 0u, s, d_coeffs, n, pw, sc.d_chunk,
+                           sc.d_block, nblocks, direct, q, sc.d_result);
 }
 
 }  // namespace kzg

@@ -1,5 +1,5 @@
 #!/bin/bash
-# HBM bytes of the quotient scan (k_poly_chunks / k_poly_blocks / k_poly_apply) from PMC counters, one counter group
+# HBM bytes of the quotient scan (k_poly_chunks / k_poly_apply) from PMC counters, one counter group
 # per pass, on ten degree-2^20 openings run one at a time (tools/prof_latency.py): FETCH_SIZE, WRITE_SIZE (KiB).
 # Algorithmic bytes: 32 B read + 32 B written per coefficient = 64 MiB per opening.
 set -o pipefail
@@ -32,5 +32,5 @@ out["_summary"] = {"fetch_bytes_uncorrected": tot_r, "fetch_bytes_x2_wide_stream
                            "(MI355X_MICROARCH.md, HBM section); the coefficients are read twice (chunk pass and replay), "
                            "the second time largely from L2 / Infinity Cache"}
 print(json.dumps(out, indent=1))
-open("gpurun_out/r02_quotient_pmc.json", "w").write(json.dumps(out, indent=1))
+open("gpurun_out/r03_quotient_pmc.json", "w").write(json.dumps(out, indent=1))
 PY
