@@ -61,7 +61,10 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offs,
 #else
 #define KZG_ACCUM_ATTR
 #endif
-__global__ void KZG_ACCUM_ATTR __launch_bounds__(kAccumBlock, 2) k_bucket_accumulate(const uint4* __restrict__ table,
+#ifndef KZG_ACCUM_MIN_BLOCKS
+#define KZG_ACCUM_MIN_BLOCKS 2
+#endif
+__global__ void KZG_ACCUM_ATTR __launch_bounds__(kAccumBlock, KZG_ACCUM_MIN_BLOCKS) k_bucket_accumulate(const uint4* __restrict__ table,
                                                                   const uint32_t* __restrict__ sorted,
                                                                   const uint32_t* __restrict__ offs, uint32_t nb,
                                                                   uint32_t lanes, uint4* __restrict__ buckets,
