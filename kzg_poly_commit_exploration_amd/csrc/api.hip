@@ -281,7 +281,8 @@ int setup_slots_impl(kzg_ctx* ctx) {
         free_slot_msm(s);
         HIP_TRY(ctx, hipMalloc(&s.d_cnt, (size_t)sort_count_entries((uint32_t)B, cfg) * 4 + 64));
         HIP_TRY(ctx, hipMalloc(&s.d_offs, ((size_t)cfg.nb * B + 1) * 4));
-        HIP_TRY(ctx, hipMalloc(&s.d_block_sums, (size_t)sort_workspace_words() * 4));  // scan block sums + tiled fine pass
+        HIP_TRY(ctx, hipMalloc(&s.d_block_sums, (size_t)sort_workspace_words() * 4));  // bin starts, chunk plan, fill counters, fine-pass table
+        HIP_TRY(ctx, hipMemset(s.d_block_sums, 0, (size_t)sort_workspace_zero_words() * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_pairs, (pairs ? pairs : 1) * 8));
         HIP_TRY(ctx, hipMalloc(&s.d_sorted, (pairs ? pairs : 1) * 4));
         HIP_TRY(ctx, hipMalloc(&s.d_buckets, (size_t)cfg.nb * B * kXyzzBytes));

@@ -65,6 +65,7 @@ constexpr size_t kHeavyHeaderBytes = 1024;  // zeroed per job: long-bucket count
 uint32_t sort_count_entries(uint32_t max_batch, MsmConfig cfg);
 uint32_t sort_max_batch(MsmConfig cfg);
 uint32_t sort_workspace_words();
+uint32_t sort_workspace_zero_words();  // leading words of d_ws that must be zero when the workspace is first used (the sort keeps them so)
 // d_header: kHeavyHeaderBytes that the job wants zeroed before its next kernel; returns true when the sort did that
 // itself (it does whenever it launches anything), false when the caller has to memset them (n == 0).
 bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int scalars_are_mont, uint32_t n, uint32_t batch,

@@ -170,14 +170,21 @@ KZG_DEV void for_each_digit(u32 k[8], MsmConfig cfg, F&& f) {
 
 // ---- two-level counting sort of the (scalar, window) pairs by bucket -------------------------
 // Scattered global atomics cap out near 2e10/s on MI355X (they execute at the memory side), which made
-// the histogram the second most expensive kernel.  The sort is therefore staged through LDS:
-//   pass 1  every workgroup takes a tile of scalars, recodes them and histograms the COARSE bin
-//           (bucket >> fine_bits) of each digit in LDS; counts go out bin-major [bin][tile]
-//   scan    exclusive scan of that table: where each tile writes inside each coarse bin
-//   pass 2  same recoding; LDS cursors hand out positions; (fine key, table reference) pairs are
-//           written into their coarse bin
-//   pass 3  the pairs of every coarse bin, in chunks: LDS histogram of the fine key -> scan -> bucket offsets,
-//           then the references are moved to their final, bucket-major position (below)
+// the histogram the second most expensive kernel.  The sort is therefore staged through LDS, in FIVE launches
+// (round 2: twelve -- three of them one-workgroup scans and two three-launch table scans, ~6 us apiece whatever they do):
+//   count    every workgroup takes a tile of scalars, recodes them and histograms the COARSE bin
+//            (bucket >> fine_bits) of each digit in LDS, then takes its range inside every bin with one global atomic
+//            per bin (the offset goes out tile-major [tile][bin]; the fill counters end up as the bin totals)
+//   spread   every workgroup derives its write cursors: a scan over the <= 2048 bin totals in LDS + its offsets (what
+//            two three-launch table scans used to prepare); workgroup 0 also leaves the bin starts and the chunk plan
+//            of the fine passes.  Then the same recoding; LDS cursors hand out positions; (fine key, table reference)
+//            pairs are written into their coarse bin
+//   fine count   the pairs of every coarse bin, in chunks: LDS histogram of the fine key -> H[bin][key][chunk]
+//   bin scan     one workgroup per bin: bins of more than kFineLocal chunks (skewed inputs only) get their H rows
+//                scanned into global positions here; empty bins get their bucket offsets
+//   fine scatter chunk (bin, j): positions from H -- for ordinary bins computed on the spot from the bin's own
+//                <= 256 x 16 entries -- then the references are moved to their final, bucket-major position (below);
+//                chunk 0 of a bin writes the bin's bucket offsets
 // No global atomics, no rank array; order inside a bucket is arbitrary (the group law is commutative,
 // the result is bit-identical).
 constexpr int kSortBlock = 256;
@@ -232,9 +239,11 @@ struct BatchGeom {
 
 __global__ void __launch_bounds__(kSortBlock) k_sort_count(const uint32_t* __restrict__ d_scalars, int is_mont,
                                                            BatchGeom bg, MsmConfig cfg, uint32_t tile,
-                                                           uint32_t tiles, uint32_t fine_bits, uint32_t coarse_bins,
-                                                           uint32_t* __restrict__ d_cnt) {
+                                                           uint32_t fine_bits, uint32_t coarse_bins,
+                                                           uint32_t* __restrict__ d_cnt, uint32_t* __restrict__ d_binfill /* zero */,
+                                                           uint32_t* __restrict__ d_header) {
     __shared__ u32 s_hist[kMaxCoarse];
+    if (blockIdx.x == 0 && threadIdx.x < kHeavyHeaderBytes / 4) d_header[threadIdx.x] = 0;  // the job's counters (one stream operation fewer per job)
     for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) s_hist[q] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * tile;
@@ -250,16 +259,77 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_count(const uint32_t* __res
         for_each_digit(k, cfg, [&](uint32_t, u32 bkt, bool) { atomicAdd(&s_hist[(pb + bkt) >> fine_bits], 1u); });
     }
     __syncthreads();
-    for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) d_cnt[(size_t)q * tiles + blockIdx.x] = s_hist[q];
+    // Every tile takes its range inside every coarse bin with ONE atomic per bin (256 ... 2048 per workgroup, each
+    // returning where the tile's pairs of that bin start): the bin fill counters end up holding the bin totals, and no
+    // kernel has to add up the count table afterwards.  Which tile comes first inside a bin is whatever order the
+    // atomics arrive in -- the order of the references of one bucket is arbitrary anyway.
+    for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) {
+        const u32 c = s_hist[q];
+        d_cnt[(size_t)blockIdx.x * coarse_bins + q] = c ? atomicAdd(&d_binfill[q], c) : 0u;  // [tile][bin]
+    }
 }
+
+// exclusive scan of 256 values, one per thread, through LDS (Hillis-Steele); total of all of them in `total`
+__device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* lds, u32& total);
+
+// pairs per chunk of the fine passes, and the workspace they share (u32 words)
+constexpr uint32_t kFineMaxChunks = 4096;            // H has kFineMaxChunks * 256 <= 2^20 entries
+constexpr uint32_t kFineLocal = 16;                  // bins of up to this many chunks are scanned by their scatter workgroups
+constexpr uint32_t kWsBinStart = 0;                  // kMaxCoarse + 1 entries: first pair of every coarse bin, then the total
+constexpr uint32_t kWsPrefix = kMaxCoarse + 8;       // kMaxCoarse + 1 entries: chunks in front of every bin, then their number
+constexpr uint32_t kWsBinFill = 2 * kMaxCoarse + 32; // kMaxCoarse entries, zero between jobs: the bins' fill counters (sort_workspace_zero_words)
+constexpr uint32_t kWsTable = 3 * kMaxCoarse + 64;   // H
+uint32_t sort_workspace_words() { return kWsTable + kFineMaxChunks * (uint32_t)kFineMax + 64; }
+uint32_t sort_workspace_zero_words() { return kWsTable; }  // what the owner clears once, when it allocates the workspace
 
 __global__ void __launch_bounds__(kSortBlock) k_sort_spread(const uint32_t* __restrict__ d_scalars, int is_mont,
                                                             BatchGeom bg, uint32_t table_stride, MsmConfig cfg,
                                                             uint32_t tile, uint32_t tiles, uint32_t fine_bits,
-                                                            uint32_t coarse_bins, const uint32_t* __restrict__ d_cnt_scanned,
+                                                            uint32_t coarse_bins, const uint32_t* __restrict__ d_cnt /* [tile][bin] */,
+                                                            const uint32_t* __restrict__ d_binfill /* bin totals */,
+                                                            uint32_t ch, uint32_t* __restrict__ d_binstart,
+                                                            uint32_t* __restrict__ d_prefix, uint32_t* __restrict__ d_total,
                                                             uint64_t* __restrict__ d_pairs) {
     __shared__ u32 s_cur[kMaxCoarse];
-    for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) s_cur[q] = d_cnt_scanned[(size_t)q * tiles + blockIdx.x];
+    __shared__ u32 s_scan[kSortBlock];
+    const uint32_t t = threadIdx.x;
+    // cursors of this tile: start of the bin (exclusive scan of the bin totals, <= 2048 values, in LDS) + the offset
+    // the tile took inside the bin (k_sort_count).  Thread t handles the bins t + 256 s.
+    constexpr uint32_t kStripes = kMaxCoarse / kSortBlock;
+    u32 below[kStripes], all[kStripes];
+#pragma unroll
+    for (uint32_t s = 0; s < kStripes; s++) {
+        const uint32_t q = t + s * kSortBlock;
+        all[s] = q < coarse_bins ? d_binfill[q] : 0u;
+        below[s] = q < coarse_bins ? d_cnt[(size_t)blockIdx.x * coarse_bins + q] : 0u;
+    }
+    u32 carry = 0, chunk_carry = 0;
+#pragma unroll
+    for (uint32_t s = 0; s < kStripes; s++) {
+        if (s * kSortBlock >= coarse_bins) break;  // (uniform)
+        const uint32_t q = t + s * kSortBlock;
+        u32 stripe_total;
+        const u32 start = carry + block_exclusive_scan_256(all[s], s_scan, stripe_total);
+        __syncthreads();
+        if (q < coarse_bins) s_cur[q] = start + below[s];
+        if (blockIdx.x == 0) {  // what the fine passes need: bin starts and their chunk plan
+            const u32 nch = q < coarse_bins ? (all[s] + ch - 1) / ch : 0u;
+            u32 chunk_total;
+            const u32 cstart = chunk_carry + block_exclusive_scan_256(nch, s_scan, chunk_total);
+            __syncthreads();
+            if (q < coarse_bins) {
+                d_binstart[q] = start;
+                d_prefix[q] = cstart;
+            }
+            chunk_carry += chunk_total;
+        }
+        carry += stripe_total;
+    }
+    if (blockIdx.x == 0 && t == 0) {
+        d_binstart[coarse_bins] = carry;
+        d_prefix[coarse_bins] = chunk_carry;
+        *d_total = carry;
+    }
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * tile;
     const uint64_t total = (uint64_t)bg.n * bg.batch;
@@ -281,21 +351,14 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_spread(const uint32_t* __re
     }
 }
 
-// ---- pass 3, tiled: every coarse bin [rs, re) of d_pairs is cut into chunks of `ch` pairs, one workgroup per
+// ---- fine passes, tiled: every coarse bin [rs, re) of d_pairs is cut into chunks of `ch` pairs, one workgroup per
 // chunk, so that a bin holding most of the references (a 0/1 polynomial puts ALL of them into one bucket) is
-// sorted by as many workgroups as a uniform input uses.  Same count -> scan -> scatter shape as passes 1-2:
-//   plan     chunks per bin, exclusive scan -> prefix[bin] (one workgroup, <= 2048 bins)
+// sorted by as many workgroups as a uniform input uses.
 //   count    chunk (bin, j): LDS histogram of the fine key -> H[prefix[bin]*fine + key*nch(bin) + j]
-//   scan     exclusive scan of H: bins are consecutive, and inside a bin the order is key-major, chunk-minor,
-//            which is exactly the final order -> H becomes the global position of every (bucket, chunk) run
-//   offsets  d_offs[bucket] = H[.. key*nch + 0] (bin start for bins without pairs)
+//   order    inside a bin the final order is key-major, chunk-minor: exactly the memory order of the bin's H entries,
+//            so a position = bin start + exclusive prefix over the bin's H.  Ordinary bins (<= kFineLocal chunks)
+//            leave that to their scatter workgroups; k_fine_binscan does it for the others
 //   scatter  chunk (bin, j): LDS cursors from H, references to their final position
-constexpr uint32_t kFineMaxChunks = 4096;            // H has kFineMaxChunks * 256 <= 2^20 entries (scan limit)
-constexpr uint32_t kWsBlockSums = 0;                 // workspace layout, u32 words
-constexpr uint32_t kWsPrefix = 1024;                 // kMaxCoarse + 1 entries
-constexpr uint32_t kWsDummy = kWsPrefix + kMaxCoarse + 8;
-constexpr uint32_t kWsTable = 4096;
-uint32_t sort_workspace_words() { return kWsTable + kFineMaxChunks * (uint32_t)kFineMax + 64; }
 
 // pairs per chunk: at most 2048 chunks come from the length, at most coarse_bins (<= 2048) from rounding up per bin
 static uint32_t fine_chunk_len(uint64_t max_pairs) {
@@ -309,52 +372,12 @@ static uint32_t fine_chunk_len(uint64_t max_pairs) {
     return (uint32_t)(ch < 4096 ? 4096 : ch);
 }
 
-KZG_DEV uint32_t bin_start(const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles, uint32_t coarse_bins, uint32_t bin,
-                           uint32_t total) {
-    return bin < coarse_bins ? d_cnt_scanned[(size_t)bin * tiles] : total;
-}
-
-__global__ void __launch_bounds__(1024) k_fine_plan(const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
-                                                    uint32_t coarse_bins, const uint32_t* __restrict__ d_total,
-                                                    uint32_t ch, uint32_t* __restrict__ d_prefix,
-                                                    uint32_t* __restrict__ d_header) {
-    __shared__ u32 lds[1024];
-    const int t = threadIdx.x;
-    if ((uint32_t)t < kHeavyHeaderBytes / 4) d_header[t] = 0;  // the job's counters (one stream operation fewer per job)
-    const uint32_t total = *d_total;
-    u32 v[2];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        uint32_t bin = 2 * t + q;
-        if (bin < coarse_bins) {
-            uint32_t rs = bin_start(d_cnt_scanned, tiles, coarse_bins, bin, total);
-            uint32_t re = bin_start(d_cnt_scanned, tiles, coarse_bins, bin + 1, total);
-            v[q] = (re - rs + ch - 1) / ch;
-        } else {
-            v[q] = 0;
-        }
-    }
-    u32 sum = v[0] + v[1];
-    lds[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        u32 add = t >= off ? lds[t - off] : 0u;
-        __syncthreads();
-        lds[t] += add;
-        __syncthreads();
-    }
-    u32 ex = lds[t] - sum;
-    if (2u * t < coarse_bins) d_prefix[2 * t] = ex;
-    if (2u * t + 1 < coarse_bins) d_prefix[2 * t + 1] = ex + v[0];
-    if (t == 1023) d_prefix[coarse_bins] = lds[1023];
-}
-
 // chunk k -> (bin, first pair, last pair, chunks of the bin, index inside the bin); false when k is past the end
 struct FineChunk {
     uint32_t bin, beg, end, nch, j, base;
 };
-KZG_DEV bool locate_chunk(uint32_t k, const uint32_t* __restrict__ d_prefix, const uint32_t* __restrict__ d_cnt_scanned,
-                          uint32_t tiles, uint32_t coarse_bins, uint32_t total, uint32_t ch, FineChunk& c) {
+KZG_DEV bool locate_chunk(uint32_t k, const uint32_t* __restrict__ d_prefix, const uint32_t* __restrict__ d_binstart,
+                          uint32_t coarse_bins, uint32_t ch, FineChunk& c) {
     if (k >= d_prefix[coarse_bins]) return false;
     uint32_t lo = 0, hi = coarse_bins;  // smallest hi with prefix[hi] > k; prefix[lo] <= k
     while (hi - lo > 1) {
@@ -365,22 +388,23 @@ KZG_DEV bool locate_chunk(uint32_t k, const uint32_t* __restrict__ d_prefix, con
     c.base = d_prefix[lo];
     c.nch = d_prefix[lo + 1] - c.base;
     c.j = k - c.base;
-    uint32_t rs = bin_start(d_cnt_scanned, tiles, coarse_bins, lo, total);
-    uint32_t re = bin_start(d_cnt_scanned, tiles, coarse_bins, lo + 1, total);
+    const uint32_t rs = d_binstart[lo], re = d_binstart[lo + 1];
     c.beg = rs + c.j * ch;
     c.end = (re - c.beg < ch) ? re : c.beg + ch;
     return true;
 }
 
 __global__ void __launch_bounds__(kSortBlock) k_fine_count(const uint64_t* __restrict__ d_pairs,
-                                                           const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
-                                                           uint32_t fine_bits, uint32_t coarse_bins,
-                                                           const uint32_t* __restrict__ d_total, uint32_t ch,
+                                                           const uint32_t* __restrict__ d_binstart, uint32_t fine_bits,
+                                                           uint32_t coarse_bins, uint32_t ch,
                                                            const uint32_t* __restrict__ d_prefix,
-                                                           uint32_t* __restrict__ d_table) {
+                                                           uint32_t* __restrict__ d_table, uint32_t* __restrict__ d_binfill) {
     __shared__ u32 s_hist[kFineMax];
+    // the bin fill counters have been consumed (k_sort_spread is complete): zero again for the slot's next job
+    if (blockIdx.x == 0)
+        for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) d_binfill[q] = 0;
     FineChunk c;
-    if (!locate_chunk(blockIdx.x, d_prefix, d_cnt_scanned, tiles, coarse_bins, *d_total, ch, c)) return;
+    if (!locate_chunk(blockIdx.x, d_prefix, d_binstart, coarse_bins, ch, c)) return;
     const uint32_t fine = 1u << fine_bits;
     if (threadIdx.x < fine) s_hist[threadIdx.x] = 0;
     __syncthreads();
@@ -389,18 +413,35 @@ __global__ void __launch_bounds__(kSortBlock) k_fine_count(const uint64_t* __res
     if (threadIdx.x < fine) d_table[(size_t)c.base * fine + (size_t)threadIdx.x * c.nch + c.j] = s_hist[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(256) k_fine_offsets(const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
-                                                      uint32_t fine_bits, uint32_t coarse_bins, uint32_t nb_total,
-                                                      const uint32_t* __restrict__ d_total,
-                                                      const uint32_t* __restrict__ d_prefix,
-                                                      const uint32_t* __restrict__ d_table_scanned,
-                                                      uint32_t* __restrict__ d_offs) {
-    uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x >= nb_total) return;
-    const uint32_t bin = x >> fine_bits, key = x & ((1u << fine_bits) - 1u);
+// One workgroup per coarse bin.  Empty bin: its buckets all start (and end) at the bin start.  A bin of more than
+// kFineLocal chunks: exclusive scan of its fine * nch entries of H in place, plus the bin start -> global positions
+// (thread t owns a contiguous run; skewed inputs only, e.g. a polynomial whose coefficients are all equal).
+__global__ void __launch_bounds__(kSortBlock) k_fine_binscan(const uint32_t* __restrict__ d_binstart, uint32_t fine_bits,
+                                                             const uint32_t* __restrict__ d_prefix,
+                                                             uint32_t* __restrict__ d_table, uint32_t* __restrict__ d_offs) {
+    __shared__ u32 s_scan[kSortBlock];
+    const uint32_t bin = blockIdx.x, t = threadIdx.x;
+    const uint32_t fine = 1u << fine_bits;
     const uint32_t base = d_prefix[bin], nch = d_prefix[bin + 1] - base;
-    d_offs[x] = nch ? d_table_scanned[((size_t)base << fine_bits) + (size_t)key * nch]
-                    : bin_start(d_cnt_scanned, tiles, coarse_bins, bin, *d_total);
+    const uint32_t rs = d_binstart[bin];
+    if (nch == 0) {
+        if (t < fine) d_offs[bin * fine + t] = rs;
+        return;
+    }
+    if (nch <= kFineLocal) return;
+    u32* h = d_table + (size_t)base * fine;
+    const uint32_t len = fine * nch;
+    const uint32_t per = (len + kSortBlock - 1) / kSortBlock;
+    const uint32_t lo = t * per < len ? t * per : len, hi = lo + per < len ? lo + per : len;
+    u32 sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += h[i];
+    u32 total;
+    u32 run = rs + block_exclusive_scan_256(sum, s_scan, total);
+    for (uint32_t i = lo; i < hi; i++) {
+        const u32 v = h[i];
+        h[i] = run;
+        run += v;
+    }
 }
 
 // Scatter of one chunk, staged through LDS: the references are first ranked inside the workgroup (one LDS cursor per
@@ -410,21 +451,46 @@ __global__ void __launch_bounds__(256) k_fine_offsets(const uint32_t* __restrict
 // issued 15.7 M separate 4-byte store transactions per commitment: 145 us alone at 2^20 terms).
 constexpr uint32_t kFineStage = 4096;  // references staged per round (16 KB + 16 KB of LDS)
 __global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const uint64_t* __restrict__ d_pairs,
-                                                             const uint32_t* __restrict__ d_cnt_scanned, uint32_t tiles,
-                                                             uint32_t fine_bits, uint32_t coarse_bins,
-                                                             const uint32_t* __restrict__ d_total, uint32_t ch,
+                                                             const uint32_t* __restrict__ d_binstart,
+                                                             uint32_t fine_bits, uint32_t coarse_bins, uint32_t ch,
                                                              const uint32_t* __restrict__ d_prefix,
-                                                             const uint32_t* __restrict__ d_table_scanned,
+                                                             const uint32_t* __restrict__ d_table,
+                                                             uint32_t* __restrict__ d_offs,
                                                              uint32_t* __restrict__ d_sorted) {
     __shared__ u32 s_cur[kFineMax];    // global cursor of every fine key for this chunk
     __shared__ u32 s_cnt[kFineMax];    // round: references per key, then exclusive offsets, then local cursors
     __shared__ u32 s_ref[kFineStage];  // round: references in key order
     __shared__ u32 s_dst[kFineStage];  // round: their global positions
     FineChunk c;
-    if (!locate_chunk(blockIdx.x, d_prefix, d_cnt_scanned, tiles, coarse_bins, *d_total, ch, c)) return;
+    if (!locate_chunk(blockIdx.x, d_prefix, d_binstart, coarse_bins, ch, c)) return;
     const uint32_t fine = 1u << fine_bits;
     const uint32_t t = threadIdx.x;
-    if (t < fine) s_cur[t] = d_table_scanned[(size_t)c.base * fine + (size_t)t * c.nch + c.j];
+    {
+        // where this chunk's run of every key starts.  Ordinary bin: from the bin's own H rows (thread t = key t reads
+        // its nch <= kFineLocal counts: all of them give the key's size, those of the chunks in front give the offset
+        // inside the key's run), the keys' sizes are scanned in LDS.  Large bin: k_fine_binscan left the position.
+        u32 mine = 0;
+        if (c.nch <= kFineLocal) {
+            u32 row = 0, front = 0;
+            if (t < fine) {
+                const u32* h = d_table + (size_t)c.base * fine + (size_t)t * c.nch;
+                for (uint32_t i = 0; i < c.nch; i++) {
+                    const u32 v = h[i];
+                    row += v;
+                    if (i < c.j) front += v;
+                }
+            }
+            u32 total;
+            const u32 key_start = d_binstart[c.bin] + block_exclusive_scan_256(row, s_ref, total);
+            __syncthreads();
+            mine = key_start + front;
+            if (c.j == 0 && t < fine) d_offs[c.bin * fine + t] = key_start;
+        } else if (t < fine) {
+            mine = d_table[(size_t)c.base * fine + (size_t)t * c.nch + c.j];
+            if (c.j == 0) d_offs[c.bin * fine + t] = mine;
+        }
+        if (t < fine) s_cur[t] = mine;
+    }
     for (uint32_t r0 = c.beg; r0 < c.end; r0 += kFineStage) {
         const uint32_t r1 = (c.end - r0 < kFineStage) ? c.end : r0 + kFineStage;
         if (t < kFineMax) s_cnt[t] = 0;
@@ -494,11 +560,7 @@ __global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const uint64_t* __r
     }
 }
 
-// ---- exclusive scan of the histogram (<= 2^20 buckets): local / top / add -----------------
-constexpr int kScanBlock = 256;
-constexpr int kScanPerThread = 4;
-constexpr int kScanTile = kScanBlock * kScanPerThread;
-
+// ---- exclusive scan of 256 values, one per thread -------------------------------------------------------------------
 __device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* lds, u32& total) {
     // Hillis-Steele over 256 values in LDS
     int t = threadIdx.x;
@@ -512,94 +574,6 @@ __device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* lds, u32& to
     }
     total = lds[255];
     return lds[t] - v;
-}
-
-__global__ void __launch_bounds__(kScanBlock) k_scan_local(const uint32_t* __restrict__ d_hist, uint32_t nb,
-                                                           uint32_t* __restrict__ d_offs,
-                                                           uint32_t* __restrict__ d_block_sums) {
-    __shared__ u32 lds[kScanBlock];
-    uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
-    u32 v[kScanPerThread];
-    u32 s = 0;
-#pragma unroll
-    for (int t = 0; t < kScanPerThread; t++) {
-        v[t] = (base + t < nb) ? d_hist[base + t] : 0u;
-        s += v[t];
-    }
-    u32 total;
-    u32 ex = block_exclusive_scan_256(s, lds, total);
-#pragma unroll
-    for (int t = 0; t < kScanPerThread; t++) {
-        if (base + t < nb) d_offs[base + t] = ex;
-        ex += v[t];
-    }
-    if (threadIdx.x == 0) d_block_sums[blockIdx.x] = total;
-}
-
-__global__ void __launch_bounds__(1024) k_scan_top(uint32_t* __restrict__ d_block_sums, uint32_t nblocks,
-                                                   uint32_t* __restrict__ d_total_out) {
-    __shared__ u32 lds[1024];
-    int t = threadIdx.x;
-    u32 v = (uint32_t)t < nblocks ? d_block_sums[t] : 0u;
-    lds[t] = v;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        u32 add = t >= off ? lds[t - off] : 0u;
-        __syncthreads();
-        lds[t] += add;
-        __syncthreads();
-    }
-    if ((uint32_t)t < nblocks) d_block_sums[t] = lds[t] - v;
-    if (t == 1023) *d_total_out = lds[1023];
-}
-
-__global__ void __launch_bounds__(kScanBlock) k_scan_add(uint32_t* __restrict__ d_offs, uint32_t nb,
-                                                         const uint32_t* __restrict__ d_block_sums) {
-    uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanPerThread;
-    u32 add = d_block_sums[blockIdx.x];
-#pragma unroll
-    for (int t = 0; t < kScanPerThread; t++)
-        if (base + t < nb) d_offs[base + t] += add;
-}
-
-// The same scan in ONE workgroup and one launch, for tables of up to kScanSingleMax entries: lane t sums its run of
-// consecutive entries, the 1024 partial sums are scanned in LDS, the run is rewritten.  A launch costs ~5 us whatever it
-// does; the three launches above are 15 us, one such kernel 4.5 us on a small table.
-constexpr uint32_t kScanSingleMax = 8192;  // (65536 entries in one workgroup took 32 us: strided runs of 64 per lane)
-__global__ void __launch_bounds__(1024) k_scan_single(uint32_t* __restrict__ d_buf, uint32_t count, uint32_t* __restrict__ d_total_out) {
-    __shared__ u32 lds[1024];
-    const uint32_t t = threadIdx.x;
-    const uint32_t per = (count + 1023u) / 1024u;
-    const uint32_t lo = t * per < count ? t * per : count, hi = lo + per < count ? lo + per : count;
-    u32 sum = 0;
-    for (uint32_t i = lo; i < hi; i++) sum += d_buf[i];
-    lds[t] = sum;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        const u32 add = t >= off ? lds[t - off] : 0u;
-        __syncthreads();
-        lds[t] += add;
-        __syncthreads();
-    }
-    u32 run = lds[t] - sum;
-    for (uint32_t i = lo; i < hi; i++) {
-        const u32 v = d_buf[i];
-        d_buf[i] = run;
-        run += v;
-    }
-    if (t == 1023) *d_total_out = lds[1023];
-}
-
-// exclusive scan of `count` u32 (count <= 2^20) in place: d_buf -> offsets, total -> *d_total
-static void scan_inplace(hipStream_t s, uint32_t* d_buf, uint32_t count, uint32_t* d_block_sums, uint32_t* d_total) {
-    if (count <= kScanSingleMax) {
-        hipLaunchKernelGGL(k_scan_single, dim3(1), dim3(1024), 0, s, d_buf, count, d_total);
-        return;
-    }
-    uint32_t nblocks = (count + kScanTile - 1) / kScanTile;
-    hipLaunchKernelGGL(k_scan_local, dim3(nblocks), dim3(kScanBlock), 0, s, d_buf, count, d_buf, d_block_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(1024), 0, s, d_block_sums, nblocks, d_total);
-    hipLaunchKernelGGL(k_scan_add, dim3(nblocks), dim3(kScanBlock), 0, s, d_buf, count, d_block_sums);
 }
 
 // ---- small inputs: the whole sort in one workgroup ----------------------------------------------------------
@@ -685,28 +659,23 @@ bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, u
     const uint32_t nb_total = cfg.nb * batch;
     SortGeom g = sort_geometry((uint64_t)n * batch, nb_total, cfg);
     BatchGeom bg{n, batch, stride, cfg.nb};
-    uint32_t* d_block_sums = d_ws + kWsBlockSums;
+    uint32_t* d_binstart = d_ws + kWsBinStart;
     uint32_t* d_prefix = d_ws + kWsPrefix;
     uint32_t* d_table = d_ws + kWsTable;
     uint32_t* d_total = d_offs + nb_total;  // number of references, also the end of the offsets
-    hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, cfg, g.tile,
-                       g.tiles, g.fine_bits, g.coarse_bins, d_cnt);
-    scan_inplace(s, d_cnt, g.coarse_bins * g.tiles, d_block_sums, d_total);
-    hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg,
-                       g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_pairs);
     const uint64_t max_pairs = (uint64_t)n * batch * cfg.max_digits;
     const uint32_t ch = fine_chunk_len(max_pairs);
     const uint32_t max_chunks = (uint32_t)((max_pairs + ch - 1) / ch) + g.coarse_bins;  // <= kFineMaxChunks
-    const uint32_t fine = 1u << g.fine_bits;
-    hipLaunchKernelGGL(k_fine_plan, dim3(1), dim3(1024), 0, s, d_cnt, g.tiles, g.coarse_bins, d_total, ch, d_prefix, d_header);
-    hipLaunchKernelGGL(k_fine_count, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
-                       g.coarse_bins, d_total, ch, d_prefix, d_table);
-    // entries past the last chunk are stale; an exclusive scan never lets them reach the valid prefix
-    scan_inplace(s, d_table, max_chunks * fine, d_block_sums, d_ws + kWsDummy);
-    hipLaunchKernelGGL(k_fine_offsets, dim3((nb_total + 255) / 256), dim3(256), 0, s, d_cnt, g.tiles, g.fine_bits,
-                       g.coarse_bins, nb_total, d_total, d_prefix, d_table, d_offs);
-    hipLaunchKernelGGL(k_fine_scatter, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_cnt, g.tiles, g.fine_bits,
-                       g.coarse_bins, d_total, ch, d_prefix, d_table, d_sorted);
+    uint32_t* d_binfill = d_ws + kWsBinFill;
+    hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, cfg, g.tile,
+                       g.fine_bits, g.coarse_bins, d_cnt, d_binfill, d_header);
+    hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg,
+                       g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_binfill, ch, d_binstart, d_prefix, d_total, d_pairs);
+    hipLaunchKernelGGL(k_fine_count, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_binstart, g.fine_bits,
+                       g.coarse_bins, ch, d_prefix, d_table, d_binfill);
+    hipLaunchKernelGGL(k_fine_binscan, dim3(g.coarse_bins), dim3(kSortBlock), 0, s, d_binstart, g.fine_bits, d_prefix, d_table, d_offs);
+    hipLaunchKernelGGL(k_fine_scatter, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_binstart, g.fine_bits,
+                       g.coarse_bins, ch, d_prefix, d_table, d_offs, d_sorted);
     return true;
 }
 
