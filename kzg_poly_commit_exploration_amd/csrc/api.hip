@@ -95,8 +95,6 @@ struct Slot {
 
 }  // namespace
 
-__global__ void k_reduce_gate(uint32_t* sink);  // defined below
-
 struct kzg_ctx {
     // a multi-device context (kzg_ctx_create_multi) only carries this pointer: its calls are sharded over the
     // single-device contexts inside (multi.hip)
@@ -130,7 +128,6 @@ struct kzg_ctx {
     // the light kernels of the other slots (sort, quotient); the reservation only matters for builds under
     // 170 VGPRs (a 168-VGPR build with 10 spilled registers measured 9 % slower with three slots in flight).
     uint32_t accum_lds_bytes = 41u * 1024u;
-    uint32_t gate_lds_bytes = 100u * 1024u;  // k_reduce_gate (KZG_REDUCE_GATE_KB overrides, 0 disables)
     uint32_t small_lds_bytes = 48u * 1024u;  // k_small_msm's LDS reservation (raised to small_msm_lds_bytes() at creation)
     bool small_msm_off = false;              // KZG_SMALL_MSM=0: small jobs take the general multi-launch path (A/B, tests)
     bool slots_ready = false;
@@ -406,8 +403,11 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         }
         launch_bucket_finalize(st, s.d_offs, nbt, lanes, s.d_part_a, s.d_part_b, s.d_buckets, s.d_heavy_ws, s.d_small + 26,
                                finalize_group_size(nbt));
-        // (gating the finalisation as well measured 3-5 % slower: it is short and wants to run at once)
-        if (ctx->gate_lds_bytes && !alone) hipLaunchKernelGGL(k_reduce_gate, dim3(1), dim3(64), ctx->gate_lds_bytes, st, (uint32_t*)nullptr);
+        // (Rounds 1-2 put a gate kernel here that deferred the reduction trees to the tail of the next slot's
+        // accumulation: worth 20 % with round 1's 206-VGPR accumulation kernel, beside which the trees could become
+        // resident; the 243-VGPR kernel fills the register file, the trees cannot start beside it whatever the stream
+        // order says, and with or without a gate -- LDS-sized or a device-side count of running workgroups -- round 3
+        // measured 409 / 384 against 408 / 383 and 414 / 386 against 415 / 386 commitments / proofs per second.  Retired.)
         launch_tree_sums_two_stage(st, stage1, 2, stage2, 4, (uint32_t*)s.d_heavy_ws + 64, alone);
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 5], st));
@@ -495,22 +495,6 @@ bool host_tail_nonzero(const uint64_t* coeffs, size_t from, size_t n) {
 
 }  // namespace
 
-// Gate between a slot's bucket finalisation and its reduction trees: one workgroup that asks for more LDS than a CU
-// has left while TWO accumulation workgroups (41 KB each) live on it.  With the next slot's accumulation at full
-// occupancy the gate -- and, in stream order, the ~180-VGPR tree kernels behind it -- waits until that kernel's
-// first workgroups retire and its tail leaves half of every SIMD idle anyway.  Without it the trees start in the
-// accumulation's first phase, pin one of the two wave slots of many SIMDs for their whole latency-bound run and
-// cost the accumulation 0.85 ms (244 instead of 305 commitments/s).  Alone on the chip the
-// gate passes at once.
-__global__ void k_reduce_gate(uint32_t* sink) {
-    extern __shared__ uint32_t gate_lds[];
-    if (sink) {
-        gate_lds[threadIdx.x] = threadIdx.x;
-        __syncthreads();
-        sink[0] = gate_lds[63 - threadIdx.x];
-    }
-}
-
 // a tiny kernel for the device-pointer entry points: any non-zero Fr in [from, n)?
 __global__ void k_tail_nonzero(const uint32_t* __restrict__ c, uint64_t from, uint64_t n, uint32_t* __restrict__ flag) {
     uint64_t i = from + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -592,7 +576,6 @@ int kzg_ctx_create(int device, kzg_ctx** out) {
     ctx->device = device;
     if (const char* v = std::getenv("KZG_SERIALIZE_ACCUM")) ctx->serialize_accum = std::atoi(v) != 0;
     if (const char* v = std::getenv("KZG_ACCUM_LDS_KB")) ctx->accum_lds_bytes = (uint32_t)std::atoi(v) * 1024u;
-    if (const char* v = std::getenv("KZG_REDUCE_GATE_KB")) ctx->gate_lds_bytes = (uint32_t)std::atoi(v) * 1024u;
     if (const char* v = std::getenv("KZG_SMALL_MSM")) ctx->small_msm_off = std::atoi(v) == 0;
     if (const char* v = std::getenv("KZG_HOST_TRACE")) ctx->host_trace = std::atoi(v) != 0;
     if (hipFuncSetAttribute(small_msm_kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)small_msm_lds_bytes()) == hipSuccess)
@@ -602,14 +585,6 @@ int kzg_ctx_create(int device, kzg_ctx** out) {
     if (!poly_prepare_device()) {
         delete ctx;
         return KZG_ERR_HIP;  // the quotient kernels could not be launched on this device
-    }
-    if (ctx->gate_lds_bytes > 64u * 1024u) {
-        // more than the default 64 KB of dynamic LDS per workgroup (gfx950 has 160 KB per CU)
-        if (hipFuncSetAttribute((const void*)k_reduce_gate, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)ctx->gate_lds_bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            ctx->gate_lds_bytes = 64u * 1024u;
-        }
     }
     *out = ctx;
     return KZG_OK;
