@@ -229,6 +229,12 @@ int kzg_g1_compress(const uint64_t p1[18], uint8_t out[48]);
  * check only, as blst.  Next-row component. */
 int kzg_g1_uncompress(const uint8_t in[48], uint64_t out_p1[18]);
 
+/* The G2 half of SetupArtifact `index` on the host: [s^index mod r]G2 as a blst_p2 (36 x u64: x, y, z in Fp2,
+ * Montgomery, z = 1), s = secret read big-endian (reference src/trusted_setup.rs:20-28, 40-53, 64-72).  A verifier
+ * only ever reads index 1 (src/polynomial.rs:284): this closes the commit -> open -> verify round trip of
+ * src/lib.rs:16-33 for a host that has no blst.  ~0.5 ms. */
+int kzg_srs_g2_at(const uint8_t secret_be[32], uint64_t index, uint64_t out_p2[36]);
+
 /* Evaluation::verify_proof (reference src/polynomial.rs:276-294):
  *     e(proof, [s]G2 - [z]G2) == e(commitment - [y]G1, G2)
  * commitment, proof: blst_p1; z = evaluation.point, y = evaluation.result: blst_fr (Montgomery);

@@ -17,7 +17,7 @@ import numpy as np
 
 __all__ = [
     "Engine", "Scalar", "G1Point", "Polynomial", "Evaluation", "SetupArtifactsGenerator", "KzgError",
-    "R_MODULUS", "lib_path", "load_library", "ABI_SYMBOLS",
+    "R_MODULUS", "lib_path", "load_library", "ABI_SYMBOLS", "srs_g2_at", "verify_proof", "verify_proof_batch",
 ]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "kzg_set_max_batch", "kzg_max_batch", "kzg_commit_batch_submit", "kzg_wait_batch",
     "kzg_open_batch_submit", "kzg_wait_open_batch", "kzg_g1_uncompress",
     "kzg_dev_alloc", "kzg_dev_free", "kzg_dev_upload", "kzg_dev_download",
-    "kzg_g1_sum", "kzg_g1_compress", "kzg_verify_proof", "kzg_verify_proof_batch", "kzg_set_timing", "kzg_get_times", "kzg_msm_config",
+    "kzg_g1_sum", "kzg_g1_compress", "kzg_srs_g2_at", "kzg_verify_proof", "kzg_verify_proof_batch", "kzg_set_timing", "kzg_get_times", "kzg_msm_config",
 ]
 
 
@@ -129,6 +129,7 @@ def load_library():
         "kzg_g1_compress": (i, [vp, vp]),
         "kzg_set_timing": (i, [vp, i]),
         "kzg_get_times": (i, [vp, i, C.POINTER(KernelTimes)]),
+        "kzg_srs_g2_at": (i, [u8p, C.c_uint64, vp]),
         "kzg_verify_proof": (i, [vp, vp, vp, vp, vp, C.POINTER(i)]),
         "kzg_verify_proof_batch": (i, [vp, vp, vp, vp, vp, sz, vp]),
         "kzg_msm_config": (i, [vp, C.POINTER(i), C.POINTER(i), C.POINTER(sz), C.POINTER(i)]),
@@ -551,6 +552,15 @@ class SetupArtifactsGenerator:
         eng = engine or Engine(self.device)
         eng.srs_generate(self.secret, n)
         return eng
+
+
+def srs_g2_at(secret_be, index=1):
+    """kzg_srs_g2_at: the G2 half of SetupArtifact `index`, [s^index]G2, as a blst_p2 (36 x uint64) -- what
+    Evaluation::verify_proof reads from setup_artifacts[1] (src/polynomial.rs:284)."""
+    lib = load_library()
+    out = np.zeros(36, dtype=np.uint64)
+    _check(lib.kzg_srs_g2_at(bytes(secret_be), int(index), _ptr(out)))
+    return out
 
 
 def verify_proof(commitment, proof, z, y, s_g2):

@@ -26,6 +26,7 @@
 #include "../../include/kzg_mi355x.h"
 #include "engine.h"
 #include "host_field.hpp"
+#include "host_fr.hpp"
 #include "host_pairing.hpp"
 
 using namespace kzg;
@@ -1740,6 +1741,27 @@ int kzg_verify_proof_batch(const uint64_t* commitments_p1, const uint64_t* proof
         if (results[i] < 0) return KZG_ERR_INVALID_ARG;
         valid[i] = results[i];
     }
+    return KZG_OK;
+}
+
+// SetupArtifact k's G2 half on the host: [s^k mod r]G2 (reference src/trusted_setup.rs:40-53 for the power, :64-72 for
+// the point; s = secret read big-endian, src/trusted_setup.rs:20-28)
+int kzg_srs_g2_at(const uint8_t secret_be[32], uint64_t index, uint64_t out_p2[36]) {
+    if (!secret_be || !out_p2) return KZG_ERR_INVALID_ARG;
+    hf::Fr s;
+    for (int w = 0; w < 4; w++) {
+        uint64_t v = 0;
+        for (int b = 0; b < 8; b++) v = (v << 8) | secret_be[24 - 8 * w + b];
+        s.l[w] = v;
+    }
+    uint64_t br = 0;
+    while (hf::fr_geq(s, hf::kFrMod)) s = hf::fr_raw_sub(s, hf::kFrMod, br);  // 2^256 < 3 r
+    static const hf::Fr kR2 = {{0xc999e990f3f29c6dULL, 0x2b6cedcb87925c23ULL, 0x05d314967254398fULL, 0x0748d9d99f59ff11ULL}};
+    const hf::Fr power = hf::fr_pow(hf::fr_mul(s, kR2), index);  // Montgomery form of s^index
+    uint64_t e[4];
+    hf::fr_from_mont(power.l, e);
+    const hf::P2 q = hf::p2_normalize(hf::p2_mul(hf::p2_generator(), e));
+    std::memcpy(out_p2, &q, sizeof q);
     return KZG_OK;
 }
 

@@ -372,6 +372,81 @@ inline P1 p1_generator() {
     return g;
 }
 
+// ---- G2 on the host: the one G2 element a verifier needs, setup_artifacts[1].g2 = [s]G2 ---------------------------
+// (reference src/trusted_setup.rs:64-72 computes [s^k]G2 for every k with blst_p2_mult; only k = 1 is ever read,
+// src/polynomial.rs:284).  Jacobian coordinates over Fp2, a = 0: dbl-2009-l / add-2007-bl, complete handling.
+struct P2 {  // blst_p2 layout: x, y, z in Fp2 (a + b u, each Montgomery); z == 0 <=> infinity
+    Fp2 x, y, z;
+    bool is_inf() const { return z.a.is_zero() && z.b.is_zero(); }
+};
+static_assert(sizeof(P2) == 288, "blst_p2 is 36 x u64");
+inline bool fp2_is_zero(const Fp2& x) { return x.a.is_zero() && x.b.is_zero(); }
+inline P2 p2_inf() {
+    P2 r;
+    std::memset(&r, 0, sizeof r);
+    return r;
+}
+inline P2 p2_double(const P2& p) {
+    if (p.is_inf() || fp2_is_zero(p.y)) return p2_inf();
+    const Fp2 A = fp2_sqr(p.x), B = fp2_sqr(p.y), C = fp2_sqr(B);
+    const Fp2 t = fp2_sqr(p.x + B) - A - C, D = t + t, E = A + A + A, F = fp2_sqr(E);
+    P2 r;
+    r.x = F - D - D;
+    Fp2 C8 = C + C;
+    C8 = C8 + C8;
+    C8 = C8 + C8;
+    r.y = fp2_mul(E, D - r.x) - C8;
+    const Fp2 yz = fp2_mul(p.y, p.z);
+    r.z = yz + yz;
+    return r;
+}
+inline P2 p2_add(const P2& a, const P2& b) {
+    if (a.is_inf()) return b;
+    if (b.is_inf()) return a;
+    const Fp2 z1z1 = fp2_sqr(a.z), z2z2 = fp2_sqr(b.z);
+    const Fp2 u1 = fp2_mul(a.x, z2z2), u2 = fp2_mul(b.x, z1z1);
+    const Fp2 s1 = fp2_mul(fp2_mul(a.y, b.z), z2z2), s2 = fp2_mul(fp2_mul(b.y, a.z), z1z1);
+    const Fp2 h = u2 - u1, rr = s2 - s1;
+    if (fp2_is_zero(h)) return fp2_is_zero(rr) ? p2_double(a) : p2_inf();
+    const Fp2 hh = fp2_sqr(h), hhh = fp2_mul(h, hh), v = fp2_mul(u1, hh);
+    P2 r;
+    r.x = fp2_sqr(rr) - hhh - v - v;
+    r.y = fp2_mul(rr, v - r.x) - fp2_mul(s1, hhh);
+    r.z = fp2_mul(fp2_mul(a.z, b.z), h);
+    return r;
+}
+inline P2 p2_normalize(const P2& p) {  // z = 1
+    if (p.is_inf()) return p2_inf();
+    const Fp2 zi = fp2_inv(p.z), zi2 = fp2_sqr(zi);
+    P2 r;
+    r.x = fp2_mul(p.x, zi2);
+    r.y = fp2_mul(fp2_mul(p.y, zi2), zi);
+    r.z = fp2_one();
+    return r;
+}
+// k * Q for a canonical little-endian 256-bit scalar, 4-bit fixed windows
+inline P2 p2_mul(const P2& q, const uint64_t k[4]) {
+    P2 tab[16];
+    tab[0] = p2_inf();
+    tab[1] = q;
+    for (int i = 2; i < 16; ++i) tab[i] = (i & 1) ? p2_add(tab[i - 1], q) : p2_double(tab[i / 2]);
+    P2 acc = p2_inf();
+    for (int i = 63; i >= 0; --i) {
+        acc = p2_double(p2_double(p2_double(p2_double(acc))));
+        const unsigned d = (unsigned)(k[i >> 4] >> (4 * (i & 15))) & 15u;
+        if (d) acc = p2_add(acc, tab[d]);
+    }
+    return acc;
+}
+inline P2 p2_generator() {
+    const G2Affine g = g2_generator();
+    P2 r;
+    r.x = g.x;
+    r.y = g.y;
+    r.z = fp2_one();
+    return r;
+}
+
 // canonical integer (4 x u64 LE) of a blst_fr in Montgomery form (R = 2^256): one Montgomery reduction
 inline void fr_from_mont(const uint64_t a[4], uint64_t out[4]) {
     static const uint64_t r[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};

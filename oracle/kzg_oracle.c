@@ -387,71 +387,100 @@ void oracle_bench_input_point(ofr *out, uint64_t degree) { /* benches/evaluation
 }
 
 /* ------------------------------------------------------------------ CPU bucket MSM (strong baseline)
- * Unsigned c-bit windows, Jacobian buckets, windows distributed over pthreads.  Computes the same
- * group element as oracle_commit_naive; it is a baseline and a cross-check, not a restatement. */
+ * Unsigned c-bit windows, Jacobian buckets; the work is cut into (window, point range) jobs over pthreads so that
+ * every host core gets one (windows alone are ~19 jobs).  Computes the same group element as oracle_commit_naive; it
+ * is a baseline and a cross-check, not a restatement. */
 typedef struct {
-    const ofr *c; size_t n; const void *srs; size_t stride;
-    const uint8_t *canon; int cbits; int nwin; int w0, w1; op1 *winsum;
+    const ofr *c; size_t i0, i1; const void *srs; size_t stride;
+    const uint8_t *canon; int cbits; int w; op1 *partial;
 } pip_job;
+typedef struct {
+    pip_job *jobs; int njobs; int next; pthread_mutex_t mu;
+} pip_queue;
 
-static void *pip_worker(void *arg) {
-    pip_job *J = (pip_job *)arg;
+static void pip_run(pip_job *J, op1 *bk) {
     size_t nb = ((size_t)1 << J->cbits) - 1;
-    op1 *bk = (op1 *)malloc(sizeof(op1) * nb);
-    for (int w = J->w0; w < J->w1; w++) {
-        memset(bk, 0, sizeof(op1) * nb);
-        for (size_t i = 0; i < J->n; i++) {
-            const uint8_t *s = J->canon + 32 * i;
-            size_t bit = (size_t)w * J->cbits;
-            unsigned d = 0;
-            for (int k = J->cbits - 1; k >= 0; k--) {
-                size_t bi = bit + k;
-                unsigned v = bi < 256 ? (s[bi >> 3] >> (bi & 7)) & 1 : 0;
-                d = (d << 1) | v;
-            }
-            if (d) oracle_p1_add_or_double(&bk[d - 1], &bk[d - 1], srs_at(J->srs, J->stride, i));
+    memset(bk, 0, sizeof(op1) * nb);
+    for (size_t i = J->i0; i < J->i1; i++) {
+        const uint8_t *s = J->canon + 32 * i;
+        size_t bit = (size_t)J->w * J->cbits;
+        unsigned d = 0;
+        for (int k = J->cbits - 1; k >= 0; k--) {
+            size_t bi = bit + k;
+            unsigned v = bi < 256 ? (s[bi >> 3] >> (bi & 7)) & 1 : 0;
+            d = (d << 1) | v;
         }
-        op1 run, acc;
-        memset(&run, 0, sizeof run); memset(&acc, 0, sizeof acc);
-        for (size_t b = nb; b-- > 0;) {
-            oracle_p1_add_or_double(&run, &run, &bk[b]);
-            oracle_p1_add_or_double(&acc, &acc, &run);
-        }
-        J->winsum[w] = acc;
+        if (d) oracle_p1_add_or_double(&bk[d - 1], &bk[d - 1], srs_at(J->srs, J->stride, i));
+    }
+    op1 run, acc;
+    memset(&run, 0, sizeof run); memset(&acc, 0, sizeof acc);
+    for (size_t b = nb; b-- > 0;) {
+        oracle_p1_add_or_double(&run, &run, &bk[b]);
+        oracle_p1_add_or_double(&acc, &acc, &run);
+    }
+    *J->partial = acc;
+}
+static void *pip_worker(void *arg) {
+    pip_queue *Q = (pip_queue *)arg;
+    op1 *bk = NULL;
+    for (;;) {
+        pthread_mutex_lock(&Q->mu);
+        int k = Q->next < Q->njobs ? Q->next++ : -1;
+        pthread_mutex_unlock(&Q->mu);
+        if (k < 0) break;
+        if (!bk) bk = (op1 *)malloc(sizeof(op1) * (((size_t)1 << Q->jobs[k].cbits) - 1));
+        pip_run(&Q->jobs[k], bk);
     }
     free(bk);
     return NULL;
 }
 
-int oracle_commit_pippenger(op1 *out, const ofr *c, size_t n, const void *srs, size_t stride,
-                            size_t srs_len, int threads) {
+/* threads_used (may be NULL) receives the number of threads that had a job */
+int oracle_commit_pippenger_ex(op1 *out, const ofr *c, size_t n, const void *srs, size_t stride,
+                               size_t srs_len, int threads, int *threads_used) {
     size_t degree = n == 0 ? 0 : n - 1;
     if (degree + 1 > srs_len) return ORACLE_ERR_DEGREE_TOO_HIGH;
     memset(out, 0, sizeof *out);
+    if (threads_used) *threads_used = 0;
     if (n == 0) return ORACLE_OK;
-    int cbits = 4;
-    while (((size_t)1 << (cbits + 1)) < n && cbits < 16) cbits++;
-    if (cbits > 3) cbits -= 2;
-    if (cbits < 2) cbits = 2;
+    if (threads < 1) threads = 1;
+    /* window width and point ranges: a job costs (points of its range) + 2 * 2^c additions; the jobs run `threads` at a time */
+    int cbits = 4, ranges = 1;
+    double best = 1e300;
+    for (int cb = 2; cb <= 16; cb++) {
+        int nw = (255 + cb - 1) / cb;
+        int r = threads / nw;
+        if (r < 1) r = 1;
+        if ((size_t)r > n) r = (int)n;
+        double per_job = (double)n / r + 2.0 * (double)((size_t)1 << cb);
+        double rounds = (double)((nw * r + threads - 1) / threads);
+        if (per_job * rounds < best) { best = per_job * rounds; cbits = cb; ranges = r; }
+    }
     int nwin = (255 + cbits - 1) / cbits;
+    int njobs = nwin * ranges;
     uint8_t *canon = (uint8_t *)malloc(32 * n);
     for (size_t i = 0; i < n; i++) oracle_fr_to_le_bytes(canon + 32 * i, &c[i]);
-    op1 *winsum = (op1 *)malloc(sizeof(op1) * nwin);
-    if (threads < 1) threads = 1;
-    if (threads > nwin) threads = nwin;
+    op1 *partial = (op1 *)malloc(sizeof(op1) * njobs);
+    pip_job *jobs = (pip_job *)malloc(sizeof(pip_job) * njobs);
+    for (int w = 0; w < nwin; w++)
+        for (int r = 0; r < ranges; r++)
+            jobs[w * ranges + r] = (pip_job){c, n * r / ranges, n * (r + 1) / ranges, srs, stride, canon, cbits, w, &partial[w * ranges + r]};
+    if (threads > njobs) threads = njobs;
+    pip_queue Q = {jobs, njobs, 0, PTHREAD_MUTEX_INITIALIZER};
     pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * threads);
-    pip_job *jobs = (pip_job *)malloc(sizeof(pip_job) * threads);
-    for (int t = 0; t < threads; t++) {
-        jobs[t] = (pip_job){c, n, srs, stride, canon, cbits, nwin, (nwin * t) / threads, (nwin * (t + 1)) / threads, winsum};
-        pthread_create(&th[t], NULL, pip_worker, &jobs[t]);
-    }
+    for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, pip_worker, &Q);
     for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    if (threads_used) *threads_used = threads;
     op1 acc; memset(&acc, 0, sizeof acc);
     for (int w = nwin; w-- > 0;) {
         for (int k = 0; k < cbits; k++) oracle_p1_double(&acc, &acc);
-        oracle_p1_add_or_double(&acc, &acc, &winsum[w]);
+        for (int r = 0; r < ranges; r++) oracle_p1_add_or_double(&acc, &acc, &partial[w * ranges + r]);
     }
     *out = acc;
-    free(jobs); free(th); free(winsum); free(canon);
+    free(jobs); free(th); free(partial); free(canon);
     return ORACLE_OK;
+}
+int oracle_commit_pippenger(op1 *out, const ofr *c, size_t n, const void *srs, size_t stride,
+                            size_t srs_len, int threads) {
+    return oracle_commit_pippenger_ex(out, c, n, srs, stride, srs_len, threads, NULL);
 }

@@ -78,6 +78,9 @@ int oracle_generate_proof(op1 *out, const ofr *c, size_t n, const ofr *z, const 
 /* bucket-method MSM, `threads` pthreads: the strong CPU baseline; same group element as commit_naive */
 int oracle_commit_pippenger(op1 *out, const ofr *c, size_t n, const void *srs_first, size_t stride,
                             size_t srs_len, int threads);
+/* the same; *threads_used receives how many threads had work (jobs are (window, point range) pairs) */
+int oracle_commit_pippenger_ex(op1 *out, const ofr *c, size_t n, const void *srs, size_t stride,
+                               size_t srs_len, int threads, int *threads_used);
 /* shortcut valid when the secret is known: [P(s)]G   */
 void oracle_commit_shortcut(op1 *out, const ofr *c, size_t n, const uint8_t secret_be[32]);
 

@@ -59,6 +59,7 @@ def lib():
             "oracle_quotient": (C.c_int, [vp, vp, vp, sz, vp, vp]),
             "oracle_generate_proof": (C.c_int, [vp, vp, sz, vp, vp, vp, sz, sz]),
             "oracle_commit_pippenger": (C.c_int, [vp, vp, sz, vp, sz, sz, C.c_int]),
+            "oracle_commit_pippenger_ex": (C.c_int, [vp, vp, sz, vp, sz, sz, C.c_int, C.POINTER(C.c_int)]),
             "oracle_commit_shortcut": (None, [vp, vp, sz, u8p]),
             "oracle_bench_coefficients": (None, [vp, sz]),
             "oracle_bench_input_point": (None, [vp, C.c_uint64]),
@@ -199,6 +200,16 @@ def commit_pippenger(coeffs, srs, threads=8, stride=144):
     out = p1_zeros(1)
     rc = lib().oracle_commit_pippenger(_p(out), _p(coeffs), len(coeffs), _p(srs), stride, srs.nbytes // stride, threads)
     return rc, out[0]
+
+
+def commit_pippenger_ex(coeffs, srs, threads=8, stride=144):
+    """bucket method over (window, point range) jobs; returns (rc, point, threads that had work)"""
+    coeffs = np.ascontiguousarray(coeffs, dtype=np.uint64)
+    out = p1_zeros(1)
+    used = C.c_int(0)
+    rc = lib().oracle_commit_pippenger_ex(_p(out), _p(coeffs), len(coeffs), _p(srs), stride, srs.nbytes // stride, threads,
+                                          C.byref(used))
+    return rc, out[0], used.value
 
 
 def commit_shortcut(coeffs, secret_be: bytes):

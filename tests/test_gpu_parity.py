@@ -1193,9 +1193,10 @@ def test_replicated_context_splits_batches_by_polynomial(engines, oracle, twin, 
         proofs = eng.open_batch_host(polys, zs, ys_claimed)
         assert isinstance(proofs[41], K.KzgError) and proofs[41].status == K.KZG_ERR_REMAINDER
         proofs[41] = eng.open_limbs(polys[41], zs[41], ys[41])
+        s_g2 = K.srs_g2_at(secret, 1)  # setup_artifacts[1].g2 from the library's own host side
         (xa, xb), (ya, yb) = PT.g2_mul(PT.G2, s)
         mont = lambda v: [((v << 384) % twin.P >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]  # noqa: E731
-        s_g2 = mont(xa) + mont(xb) + mont(ya) + mont(yb) + mont(1) + mont(0)
+        assert list(s_g2) == mont(xa) + mont(xb) + mont(ya) + mont(yb) + mont(1) + mont(0)  # ... checked against the twin
         assert K.verify_proof_batch(commitments, proofs, zs, ys, s_g2) == [True] * 64
         # same bytes as a single-device engine on the same SRS
         one = K.SetupArtifactsGenerator(secret).take(n)
@@ -1238,9 +1239,7 @@ def test_config5_sixteen_degree_2_20_openings_over_eight_devices(oracle, twin, g
         assert proofs[0].compress().hex() == case["proof"]
         assert len({p.compress() for p in proofs}) == batch
         commitment = K.G1Point.uncompress(bytes.fromhex(case["commit"]))
-        (xa, xb), (ya, yb) = PT.g2_mul(PT.G2, s)
-        mont = lambda v: [((v << 384) % twin.P >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(6)]  # noqa: E731
-        s_g2 = mont(xa) + mont(xb) + mont(ya) + mont(yb) + mont(1) + mont(0)
+        s_g2 = K.srs_g2_at(secret, 1)
         assert K.verify_proof_batch([commitment] * batch, proofs, zs, ys, s_g2) == [True] * batch
     finally:
         eng.close()

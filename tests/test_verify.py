@@ -101,3 +101,39 @@ def test_verify_proof_rejects_a_g2_point_off_the_curve(twin):
         raise AssertionError("accepted a malformed G2 point")
     except K.KzgError as e:
         assert e.status == K.KZG_ERR_INVALID_ARG
+
+
+def test_srs_g2_at_matches_the_pairing_twin(twin):
+    """kzg_srs_g2_at(secret, k) = [s^k mod r]G2 as a blst_p2 with z = 1 (reference src/trusted_setup.rs:40-53, 64-72):
+    index 0 is the generator, index 1 what verify_proof reads (src/polynomial.rs:284); secrets above r are reduced."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pairing_twin as PT
+
+    P, R = twin.P, twin.R
+    rnd = random.Random(36)
+    secrets = [twin.BENCH_SECRET_BE, (R - 1).to_bytes(32, "big"), (1).to_bytes(32, "big"), bytes([0xFF] * 32)] + \
+              [bytes(rnd.randrange(256) for _ in range(32)) for _ in range(3)]
+    for secret in secrets:
+        s = int.from_bytes(secret, "big") % R
+        for k in (0, 1, 2, 7):
+            want = _p2_limbs(PT.g2_mul(PT.G2, pow(s, k, R)), P)
+            got = K.srs_g2_at(secret, k)
+            assert (got == want).all(), (secret.hex(), k)
+    # [0]G2: the point at infinity, all-zero z
+    assert not K.srs_g2_at(bytes(32), 1)[24:].any()
+
+
+def test_round_trip_of_lib_rs_without_the_twin_supplying_g2(twin, oracle):
+    """src/lib.rs:16-33 with every group element from the product library's host side: [s]G2 from kzg_srs_g2_at,
+    the pairing check from kzg_verify_proof (commitment and proof from the known-secret shortcut: no GPU here)."""
+    rnd = random.Random(99)
+    R = twin.R
+    secret = bytes(rnd.randrange(256) for _ in range(32))
+    coeffs = [rnd.randrange(R) for _ in range(9)]
+    z = rnd.randrange(R)
+    y = sum(c * pow(z, i, R) for i, c in enumerate(coeffs)) % R
+    c1 = _p1(twin, oracle, twin.commit_shortcut(coeffs, secret))
+    p1 = _p1(twin, oracle, twin.proof_shortcut(coeffs, z, y, secret))
+    s_g2 = K.srs_g2_at(secret, 1)
+    assert K.Evaluation(K.Scalar(z), K.Scalar(y)).verify_proof(p1, c1, s_g2) is True
+    assert K.Evaluation(K.Scalar(z), K.Scalar((y + 1) % R)).verify_proof(p1, c1, s_g2) is False
