@@ -82,6 +82,19 @@ def bench_coefficient_limbs(n):
     return K.scalars_to_limbs(vals), vals
 
 
+def usable_host_cores():
+    """cores this process may actually use: the scheduler affinity, capped by the cgroup CPU quota (a GPU box shows 256
+    cores but grants a one-GPU job 16 of them: cpu.max = "1600000 100000")"""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return cores
+
+
 def cpu_baseline(eng, coeff_limbs, sample):
     """Oracle leg (the ONLY use of oracle/ here): the reference's algorithm -- N scalar multiplications + N
     additions, one thread (src/polynomial.rs:208-212) -- run IN FULL on a degree-2^16 polynomial of the same
@@ -99,13 +112,14 @@ def cpu_baseline(eng, coeff_limbs, sample):
     assert rc == 0
     got = eng.commit_limbs(c).compress()
     assert got == O.p1_compress(cm), "GPU and oracle disagree on the cpu_baseline sample"
-    host_cores = os.cpu_count() or 1
+    host_cores = usable_host_cores()
     out = {"value": 1.0 / (dt * n / sample), "unit": "commitments/s", "cores": 1, "kind": "port", "host_cores": host_cores,
+           "host_cores_visible": os.cpu_count() or 1,
            "sample": "degree-%d commitment (%d terms) in full, naive N x scalar-mul loop (the reference's algorithm): %.1f s = "
                      "%.4f commitments/s at that degree, bit-identical to the GPU's; value = that / %.1f (linear in N) for degree 2^20"
                      % (sample - 1, sample, dt, 1.0 / dt, n / sample),
            "measured_commitments_per_sec_at_sample_degree": 1.0 / dt}
-    # strong CPU baseline: bucket method on all host cores
+    # strong CPU baseline: bucket method on every core this process is granted
     threads = host_cores
     sample2 = min(n, 1 << 18)
     srs2 = eng.srs_read(0, sample2)
@@ -132,7 +146,27 @@ def host_pointer_path(eng, limbs, z, y, want_commit, want_proof, reps):
         got = eng.open_limbs(limbs, z, y)
     t_open = (time.perf_counter() - t0) / reps
     assert want_proof is None or got.compress().hex() == want_proof
-    return {"host_pointer_commitments_per_sec": 1.0 / t_commit, "host_pointer_proofs_per_sec": 1.0 / t_open,
+    # the same calls from 3 and 4 host threads (the reference's callers include `cargo test` threads, src/lib.rs:53, 66,
+    # 91): every call owns a stream slot of the context for its duration, so the jobs pipeline on the GPU
+    import threading
+
+    threaded = {}
+    for nthreads in (3, 4):
+        for label, fn in (("commitments", lambda: eng.commit_limbs(limbs)), ("proofs", lambda: eng.open_limbs(limbs, z, y))):
+            per = 2 * reps
+
+            def worker(fn=fn):
+                for _ in range(per):
+                    fn()
+
+            ths = [threading.Thread(target=worker) for _ in range(nthreads)]
+            t0 = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            threaded["host_pointer_%s_per_sec_%d_threads" % (label, nthreads)] = nthreads * per / (time.perf_counter() - t0)
+    return {"host_pointer_commitments_per_sec": 1.0 / t_commit, "host_pointer_proofs_per_sec": 1.0 / t_open, **threaded,
             "host_pointer_ms": {"commit": t_commit * 1e3, "open": t_open * 1e3},
             "host_pointer_note": "kzg_commit / kzg_open on pageable host memory, synchronous, one at a time (the Rust "
                                  "shim's calls); PCIe copy of the coefficients inside the timed region"}
@@ -172,9 +206,21 @@ def batch_of_openings(eng, limbs, n, degree, golden, dev, torch, np, K):
     want_p = next((x["proof"] for x in golden["bench"] if x["degree"] == degree), None)
     if want_p:
         assert K.G1Point(out[0]).compress().hex() == want_p, "batched opening 0 differs from tests/golden"
+    # the same share through the host-pointer batch (kzg_open_batch: what a multi-device context runs per device):
+    # 8 x 32 MiB of pageable coefficients uploaded in sub-batches under the kernels of the previous ones
+    flat = np.ascontiguousarray(np.broadcast_to(np.ascontiguousarray(limbs, dtype=np.uint64).reshape(1, n, 4), (8, n, 4)))
+    host_proofs = eng.open_batch_host(flat, zs, ys)
+    assert all(not isinstance(p, Exception) for p in host_proofs)
+    assert all(host_proofs[k].compress() == K.G1Point(out[k]).compress() for k in range(8)), "host-pointer batch differs from the device-resident batch"
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.open_batch_host(flat, zs, ys)
+    dth = (time.perf_counter() - t0) / reps
     eng.set_max_batch(1)
     return {"openings_batch8_per_sec": 8.0 / dt, "openings_batch8_ms": dt * 1e3,
-            "openings_batch8_note": "config 5's per-GPU share: 8 x degree-2^20 openings in one kzg_open_batch_submit, resident inputs"}
+            "openings_batch8_host_pointer_per_sec": 8.0 / dth,
+            "openings_batch8_note": "config 5's per-GPU share: 8 x degree-2^20 openings in one kzg_open_batch_submit, resident inputs; "
+                                    "host_pointer: the same through kzg_open_batch (PCIe copies inside, sub-batches of 2 pipelined through the slots)"}
 
 
 def main():
@@ -355,19 +401,19 @@ def main():
         refs = phase_ms.pop("references", [])
         madds = int(sum(refs) / max(1, len(refs)))   # one mixed addition per non-zero scalar digit (counted on the device)
         tmad = madds * MADS_PER_MADD / (avg_accum_ms * 1e-3) / 1e12 if avg_accum_ms > 0 else 0.0
-        # PMC figures are measured OFF-LINE (tools/prof_round2.sh) and only quoted when the profiled sources are the
+        # PMC figures are measured OFF-LINE (tools/prof_round3.sh) and only quoted when the profiled sources are the
         # ones that just ran (hash of msm_accum.hip + g1_30.hip.h + field30.hip.h stored with them)
         traffic = None
-        tj = offline_profile("r02_traffic.json") if (world == 1 and degree == DEGREE and batch == 1) else None
+        tj = offline_profile("r03_traffic.json") if (world == 1 and degree == DEGREE and batch == 1) else None
         if tj and tj.get("recoding", "windows") == cfg["recoding"]:
             traffic = tj.get("hbm_bytes_per_launch")
         valu_pmc = {}
-        vj = offline_profile("r02_valu_pmc.json") if (world == 1 and degree == DEGREE and batch == 1) else None
+        vj = offline_profile("r03_valu_pmc.json") if (world == 1 and degree == DEGREE and batch == 1) else None
         if vj:
             valu_pmc = {"pmc_valu_busy_percent": vj.get("VALUBusy"),
                         "pmc_valu_lane_utilization_percent": vj.get("VALUUtilization"),
                         "pmc_valu_instructions_per_mixed_addition": vj.get("valu_instructions_per_mixed_addition"),
-                        "pmc_source": "offline: profiles/r02_valu_pmc.json (tools/prof_round2.sh, same workload, same kernel sources)"}
+                        "pmc_source": "offline: profiles/r03_valu_pmc.json (tools/prof_round3.sh, same workload, same kernel sources)"}
         line = {
             "metric": "g1_msm_commitments_per_sec_degree_2^20",
             "value": args.steps * batch / elapsed,
@@ -389,7 +435,7 @@ def main():
                        "bit_exact_vs_golden": ok},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": ("offline: profiles/r02_traffic.json, same kernel sources" if traffic else None),
+                         "traffic_source": ("offline: profiles/r03_traffic.json, same kernel sources" if traffic else None),
                          "kernel": "k_bucket_accumulate", "avg_kernel_ms": avg_accum_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_source_hash": kernel_source_hash(),

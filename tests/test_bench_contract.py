@@ -29,7 +29,9 @@ def test_bench_emits_one_contract_line():
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     # the calls the Rust shim makes (host pointers) and config 5's per-GPU batch are reported beside `value`
     assert d["host_pointer_commitments_per_sec"] > 0 and d["host_pointer_proofs_per_sec"] > 0
-    assert d["openings_batch8_per_sec"] > 0
+    assert d["openings_batch8_per_sec"] > 0 and d["openings_batch8_host_pointer_per_sec"] > 0
+    # ... and from several caller threads, which occupy one stream slot each
+    assert d["host_pointer_commitments_per_sec_3_threads"] > 0 and d["host_pointer_proofs_per_sec_3_threads"] > 0
     assert r.get("kernel_source_hash")
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Copies the summaries tools/prof_round2.sh left under gpurun_out/ into profiles/r02_* (tracked), adding the hash of
+"""Copies the summaries tools/prof_round3.sh left under gpurun_out/ into profiles/r03_* (tracked), adding the hash of
 the kernel sources they were measured on (bench.py quotes the PMC figures only while that hash matches).
 Run right after the gpurun call, before touching msm_accum.hip / g1_30.hip.h / field30.hip.h again."""
 import csv
@@ -16,11 +16,11 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 h = bench.kernel_source_hash()
 
-line = [l for l in open(os.path.join(G, "r02_bench_default.log")).read().splitlines() if l.startswith("{")][-1]
+line = [l for l in open(os.path.join(G, "r03_bench_default.log")).read().splitlines() if l.startswith("{")][-1]
 d = json.loads(line)
-with open(os.path.join(P, "r02_bench.jsonl"), "w") as f:
+with open(os.path.join(P, "r03_bench.jsonl"), "w") as f:
     f.write(line + "\n")
-shutil.copy(os.path.join(G, "r02_kernel_stats.csv"), os.path.join(P, "r02_kernel_stats.csv"))
+shutil.copy(os.path.join(G, "r03_kernel_stats.csv"), os.path.join(P, "r03_kernel_stats.csv"))
 
 pm = json.load(open(os.path.join(G, "pmc_summary.json")))
 acc = next(v for k, v in pm.items() if "accumulate" in k)
@@ -40,7 +40,7 @@ traffic = {
     "hbm_read_bytes_corrected": read_b, "hbm_write_bytes": write_b, "hbm_bytes_per_launch": read_b + write_b,
     "algorithmic_bytes_per_launch": d["roofline"]["algorithmic_bytes_per_launch"], "batch": 1, "recoding": d["config"]["recoding"],
 }
-json.dump(traffic, open(os.path.join(P, "r02_traffic.json"), "w"), indent=1)
+json.dump(traffic, open(os.path.join(P, "r03_traffic.json"), "w"), indent=1)
 
 v = json.load(open(os.path.join(G, "valu_summary.json")))
 v["kernel_source_hash"] = h
@@ -48,11 +48,11 @@ v["mixed_additions_per_launch"] = madds
 if "SQ_INSTS_VALU" in v and madds:
     v["valu_instructions_per_mixed_addition"] = v["SQ_INSTS_VALU"] / (madds / 64.0)
 v["_comment"] = "VALU counters of the accumulation kernel (tools/prof_valu.sh, --steps 4 --slots 1, same workload)"
-json.dump(v, open(os.path.join(P, "r02_valu_pmc.json"), "w"), indent=1)
-print("profiles/r02_* written for kernel sources", h)
+json.dump(v, open(os.path.join(P, "r03_valu_pmc.json"), "w"), indent=1)
+print("profiles/r03_* written for kernel sources", h)
 print("kernel avg ms (bench events): %.3f   traffic %.2f GB   VALUBusy %s" % (
     d["roofline"]["avg_kernel_ms"], (read_b + write_b) / 1e9, v.get("VALUBusy")))
-with open(os.path.join(P, "r02_kernel_stats.csv")) as f:
+with open(os.path.join(P, "r03_kernel_stats.csv")) as f:
     for i, row in enumerate(csv.reader(f)):
         if i < 4:
             print(row[0][:60], row[1:4])
