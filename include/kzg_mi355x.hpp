@@ -62,7 +62,10 @@ class SetupArtifacts {  // owns one engine context = one GPU with the SRS reside
    public:
     explicit SetupArtifacts(int device = 0) { check(kzg_ctx_create(device, &ctx_)); }
     // one context over several devices: SRS split by point range, commit / open sharded transparently
-    explicit SetupArtifacts(const std::vector<int>& devices) { check(kzg_ctx_create_multi(devices.data(), (int)devices.size(), &ctx_)); }
+    // replicate_srs: every device keeps the whole SRS and batches are split by polynomial (BASELINE config 5)
+    explicit SetupArtifacts(const std::vector<int>& devices, bool replicate_srs = false) {
+        check(kzg_ctx_create_multi_ex(devices.data(), (int)devices.size(), replicate_srs ? KZG_MULTI_REPLICATE_SRS : 0u, &ctx_));
+    }
     ~SetupArtifacts() { kzg_ctx_destroy(ctx_); }
     SetupArtifacts(const SetupArtifacts&) = delete;
     SetupArtifacts& operator=(const SetupArtifacts&) = delete;
@@ -77,6 +80,13 @@ class SetupArtifacts {  // owns one engine context = one GPU with the SRS reside
     void save(const std::string& path) const { check(kzg_srs_save(ctx_, path.c_str()), ctx_); }   // binary affine cache
     void load_file(const std::string& path) { check(kzg_srs_load_file(ctx_, path.c_str()), ctx_); }
     size_t len() const { return kzg_srs_len(ctx_); }
+    size_t set_max_batch(size_t b) { check(kzg_set_max_batch(ctx_, b), ctx_); return kzg_max_batch(ctx_); }
+    // setup_artifacts[index].g2 = [s^index]G2 (src/trusted_setup.rs:64-72), computed on the host: what verify_proof reads at index 1
+    static std::array<uint64_t, 36> g2_at(const std::array<uint8_t, 32>& secret_be, uint64_t index = 1) {
+        std::array<uint64_t, 36> out{};
+        check(kzg_srs_g2_at(secret_be.data(), index, out.data()));
+        return out;
+    }
     kzg_ctx* ctx() const { return ctx_; }
 
    private:
@@ -113,6 +123,29 @@ class Polynomial {
    private:
     std::vector<Scalar> coefficients_;
 };
+
+// The loop of the reference's callers over many polynomials (src/lib.rs:16-33 once per polynomial) as ONE call:
+// `batch` polynomials of n coefficients each, polynomial p at coeffs[p * n ..]; on a multi-device context the
+// polynomials (replicated SRS) or every polynomial's ranges (range-split SRS) spread over the GPUs.
+inline std::vector<G1Point> commit_batch(const SetupArtifacts& setup, const std::vector<Scalar>& coeffs, size_t n) {
+    const size_t batch = n ? coeffs.size() / n : 0;
+    std::vector<G1Point> out(batch);
+    check(kzg_commit_batch(setup.ctx(), reinterpret_cast<const uint64_t*>(coeffs.data()), n, batch, n,
+                           reinterpret_cast<uint64_t*>(out.data())), setup.ctx());
+    return out;
+}
+// statuses[p]: KZG_OK, KZG_ERR_CONSTANT_POLY or KZG_ERR_REMAINDER -- what generate_proof would have returned for p
+inline std::vector<G1Point> open_batch(const SetupArtifacts& setup, const std::vector<Scalar>& coeffs, size_t n,
+                                       const std::vector<Scalar>& points, const std::vector<Scalar>& results, std::vector<int>& statuses) {
+    const size_t batch = points.size();
+    std::vector<G1Point> out(batch);
+    statuses.assign(batch, KZG_OK);
+    check(kzg_open_batch(setup.ctx(), reinterpret_cast<const uint64_t*>(coeffs.data()), n, batch, n,
+                         reinterpret_cast<const uint64_t*>(points.data()), reinterpret_cast<const uint64_t*>(results.data()),
+                         reinterpret_cast<uint64_t*>(out.data()), statuses.data()), setup.ctx());
+    return out;
+}
+static_assert(sizeof(G1Point) == 144 && sizeof(Scalar) == 32, "memory images of blst_p1 / blst_fr");
 
 struct Evaluation {  // src/polynomial.rs:249-253
     Scalar point, result;

@@ -69,16 +69,25 @@ struct Slot {
     void* d_pair_scratch = nullptr;  // prefix products of the affine front end (msm_accum.hip)
     void* d_heavy_ws = nullptr;   // long-bucket registry + tree buffers of msm_finalize.hip
     void* d_arena = nullptr;     // Row[] then Col[] vectors of the bucket matrix
+    // The <= 128 partial sums the host finishes are written by the last reduction kernel STRAIGHT into pinned host
+    // memory (d_final is the device's address of h_final): a copy back is a blit kernel on this runtime, and behind an
+    // accumulation kernel that fills the chip it took 1.3 ms instead of 5 us -- the host collected the job that much
+    // later, submitted the next one that much later, and its sort finished after the accumulation it should have
+    // hidden under (100-240 us of idle chip per commitment; round-3 timeline).
     void* d_final = nullptr;
-    uint64_t* h_final = nullptr;  // pinned
+    uint64_t* h_final = nullptr;  // pinned, mapped
     // polynomial workspace (grown on demand)
     size_t poly_cap = 0;
     uint32_t* d_stage = nullptr;  // coefficients copied from the host
     uint32_t* d_q = nullptr;      // quotient
     uint32_t* d_chunk = nullptr;
     uint32_t* d_block = nullptr;
+    // The job's flag words live in pinned host memory that the kernels write directly (d_small is the device's address of
+    // h_small; plain stores only -- every writer of a flag stores the same 1): no memset and no copy-back on the stream.
+    // A 256-byte copy back is a blit kernel here, and queued behind a chip-filling accumulation it sat for ~1 ms between
+    // the job's last kernel and the moment the host could collect it.
     uint32_t* d_small = nullptr;  // [0..1] flags, [8..15] P(z), [16..23] c0, [24] tail flag, [26] references
-    uint32_t* h_small = nullptr;  // pinned mirror
+    uint32_t* h_small = nullptr;  // pinned, mapped
     uint32_t* d_bsmall = nullptr;  // batched openings: 32 words per polynomial, same layout as d_small[0..31]
     uint32_t* h_bsmall = nullptr;
     size_t bsmall_cap = 0;
@@ -158,7 +167,7 @@ struct TmpStream {
 
 void free_slot_msm(Slot& s) {
     hipFree(s.d_cnt); hipFree(s.d_offs); hipFree(s.d_block_sums); hipFree(s.d_pairs); hipFree(s.d_sorted);
-    hipFree(s.d_buckets); hipFree(s.d_part_a); hipFree(s.d_part_b); hipFree(s.d_heavy_ws); hipFree(s.d_arena); hipFree(s.d_final);
+    hipFree(s.d_buckets); hipFree(s.d_part_a); hipFree(s.d_part_b); hipFree(s.d_heavy_ws); hipFree(s.d_arena);
     hipFree(s.d_pair_scratch);
     s.d_pair_scratch = nullptr;
     if (s.h_final) hipHostFree(s.h_final);
@@ -189,8 +198,8 @@ int ensure_slot_basics(kzg_ctx* ctx, Slot& s) {
     }
     for (auto& e : s.ev) HIP_TRY(ctx, hipEventCreate(&e));
     HIP_TRY(ctx, hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-    HIP_TRY(ctx, hipMalloc(&s.d_small, 64 * 4));
-    HIP_TRY(ctx, hipHostMalloc(&s.h_small, 64 * 4));
+    HIP_TRY(ctx, hipHostMalloc(&s.h_small, 64 * 4, hipHostMallocMapped));
+    HIP_TRY(ctx, hipHostGetDevicePointer((void**)&s.d_small, s.h_small, 0));
     return KZG_OK;
 }
 
@@ -290,8 +299,8 @@ int setup_slots_impl(kzg_ctx* ctx) {
             HIP_TRY(ctx, hipMalloc(&s.d_pair_scratch, pair_bytes));
         HIP_TRY(ctx, hipMalloc(&s.d_heavy_ws, heavy_workspace_bytes()));
         HIP_TRY(ctx, hipMalloc(&s.d_arena, ctx->arena_records * B * kXyzzBytes));
-        HIP_TRY(ctx, hipMalloc(&s.d_final, ctx->final_records * B * kXyzzBytes));
-        HIP_TRY(ctx, hipHostMalloc(&s.h_final, ctx->final_records * B * kXyzzBytes));
+        HIP_TRY(ctx, hipHostMalloc(&s.h_final, ctx->final_records * B * kXyzzBytes, hipHostMallocMapped));
+        HIP_TRY(ctx, hipHostGetDevicePointer(&s.d_final, s.h_final, 0));
         s.kind = SLOT_IDLE;
     }
     ctx->slots_ready = true;
@@ -412,8 +421,6 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         launch_tree_sums_two_stage(st, stage1, 2, stage2, 4, (uint32_t*)s.d_heavy_ws + 64, alone);
     }
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 5], st));
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_final, s.d_final, ctx->final_records * batch * kXyzzBytes, hipMemcpyDeviceToHost,
-                                st));
     HIP_TRY(ctx, hipGetLastError());
     return KZG_OK;
 }
@@ -502,7 +509,7 @@ __global__ void k_tail_nonzero(const uint32_t* __restrict__ c, uint64_t from, ui
     if (i >= n) return;
     const uint4* p = reinterpret_cast<const uint4*>(c) + 2 * i;
     uint4 a = p[0], b = p[1];
-    if (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) atomicOr(flag, 1u);
+    if (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) *flag = 1u;  // (host-mapped word: plain store, every writer stores 1)
 }
 
 // HIP multiplexes the streams of a process onto 4 hardware queues by default.  A context uses 4 streams of its own
@@ -609,9 +616,7 @@ void kzg_ctx_destroy(kzg_ctx* ctx) {
         if (s.stream) hipStreamSynchronize(s.stream);
         free_slot_msm(s);
         free_slot_poly(s);
-        if (s.d_small) hipFree(s.d_small);
         if (s.h_small) hipHostFree(s.h_small);
-        if (s.d_bsmall) hipFree(s.d_bsmall);
         if (s.h_bsmall) hipHostFree(s.h_bsmall);
         for (auto& e : s.ev)
             if (e) hipEventDestroy(e);
@@ -933,12 +938,7 @@ static int submit_commit_locked(kzg_ctx* ctx, int slot, const uint32_t* d_scalar
     s.tail_checked = tail_already_checked;
     std::memset(&s.times, 0, sizeof s.times);
     size_t n_msm = n < ctx->n ? n : ctx->n;
-    // The flag words only matter when there is a tail beyond the SRS to check, a trivial job to report or kernel
-    // statistics to return: a plain commitment skips their memset and their copy back (two stream operations of the
-    // ~8 a small commitment consists of) and reads zeros.
-    const bool need_small = (n > ctx->n && !tail_already_checked) || n_msm == 0 || s.timing;
-    if (need_small) HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
-    else std::memset(s.h_small, 0, 64 * 4);
+    std::memset(s.h_small, 0, 64 * 4);  // (the slot is idle: nothing in flight writes them)
     if (n > ctx->n && !tail_already_checked) {
         // reference: the Polynomial was truncated at construction (src/polynomial.rs:55-75), so only a
         // non-zero coefficient beyond the SRS makes the degree too high (src/polynomial.rs:201-205)
@@ -952,7 +952,6 @@ static int submit_commit_locked(kzg_ctx* ctx, int slot, const uint32_t* d_scalar
     }
     int rc = enqueue_msm(ctx, s, d_scalars, is_mont, n_msm, 0);
     if (rc) return rc;
-    if (need_small) HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
     s.kind = SLOT_COMMIT;
     return KZG_OK;
@@ -983,7 +982,7 @@ static int submit_open_locked(kzg_ctx* ctx, int slot, const uint32_t* d_coeffs, 
     std::memcpy(s.open_y, y, 32);
     std::memset(&s.times, 0, sizeof s.times);
     if (n == 0) {
-        HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+        std::memset(s.h_small, 0, 64 * 4);
         s.kind = SLOT_TRIVIAL;
         return KZG_OK;
     }
@@ -992,7 +991,7 @@ static int submit_open_locked(kzg_ctx* ctx, int slot, const uint32_t* d_coeffs, 
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[6], s.stream));
     // small polynomials: one launch for the scan, the flag words and c0; otherwise memset + two launches (c0 written by the first)
     if (!launch_quotient_single(s.stream, d_coeffs, (uint32_t)n, zw, n > 1 ? s.d_q : nullptr, s.d_small)) {
-        HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+        std::memset(s.h_small, 0, 64 * 4);
         PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
         launch_quotient(s.stream, d_coeffs, (uint32_t)n, zw, n > 1 ? s.d_q : nullptr, sc);
     }
@@ -1009,7 +1008,6 @@ static int submit_open_locked(kzg_ctx* ctx, int slot, const uint32_t* d_coeffs, 
         rc = enqueue_msm(ctx, s, s.d_q, 1, nq, 0);
         if (rc) return rc;
     }
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
     s.kind = nq > 0 ? SLOT_OPEN : SLOT_TRIVIAL;
     return KZG_OK;
@@ -1036,8 +1034,6 @@ static int wait_locked(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
     SlotKind kind = s.kind;
     slot_idle(ctx, s);
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
-    if (kind == SLOT_TRIVIAL)  // nothing but flags may have been enqueued
-        HIP_TRY(ctx, hipMemcpy(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost));
     if (s.timing && kind != SLOT_TRIVIAL) {
         float ms = 0;
         hipEventElapsedTime(&ms, s.ev[0], s.ev[1]); s.times.digits_ms = ms;
@@ -1127,10 +1123,9 @@ static int commit_batch_submit_locked(kzg_ctx* ctx, int slot, const void* d_coef
     s.job_batch = (uint32_t)batch;
     s.tail_checked = true;
     std::memset(&s.times, 0, sizeof s.times);
-    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    std::memset(s.h_small, 0, 64 * 4);
     int rc = enqueue_msm(ctx, s, (const uint32_t*)d_coeffs, 1, n, 0, (uint32_t)batch, stride_coeffs);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
     s.kind = SLOT_COMMIT_BATCH;
     return KZG_OK;
@@ -1201,10 +1196,10 @@ static int open_batch_submit_locked(kzg_ctx* ctx, int slot, const void* d_coeffs
     if (rc) return rc;
     if (s.bsmall_cap < batch) {
         HIP_TRY(ctx, hipStreamSynchronize(s.stream));
-        if (s.d_bsmall) hipFree(s.d_bsmall);
         if (s.h_bsmall) hipHostFree(s.h_bsmall);
-        HIP_TRY(ctx, hipMalloc(&s.d_bsmall, batch * 32 * 4));
-        HIP_TRY(ctx, hipHostMalloc(&s.h_bsmall, batch * 32 * 4));
+        s.h_bsmall = nullptr;
+        HIP_TRY(ctx, hipHostMalloc(&s.h_bsmall, batch * 32 * 4, hipHostMallocMapped));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void**)&s.d_bsmall, s.h_bsmall, 0));
         s.bsmall_cap = batch;
     }
     s.timing = ctx->timing;
@@ -1214,8 +1209,8 @@ static int open_batch_submit_locked(kzg_ctx* ctx, int slot, const void* d_coeffs
     s.tail_checked = true;
     s.open_ys.assign((const uint32_t*)ys, (const uint32_t*)ys + 8 * batch);
     std::memset(&s.times, 0, sizeof s.times);
-    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
-    HIP_TRY(ctx, hipMemsetAsync(s.d_bsmall, 0, batch * 32 * 4, s.stream));
+    std::memset(s.h_small, 0, 64 * 4);
+    std::memset(s.h_bsmall, 0, batch * 32 * 4);
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[6], s.stream));
     const size_t nq = n - 1;
     for (size_t p = 0; p < batch; p++) {
@@ -1229,8 +1224,6 @@ static int open_batch_submit_locked(kzg_ctx* ctx, int slot, const void* d_coeffs
     if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[7], s.stream));
     rc = enqueue_msm(ctx, s, s.d_q, 1, nq, 0, (uint32_t)batch, nq);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_bsmall, s.d_bsmall, batch * 32 * 4, hipMemcpyDeviceToHost, s.stream));
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipEventRecord(s.done, s.stream));
     s.kind = SLOT_OPEN_BATCH;
     return KZG_OK;
@@ -1506,11 +1499,11 @@ int ctx_open_slice_begin(kzg_ctx* ctx, const uint64_t* slice, size_t len, const 
         lk.unlock();
         uint32_t zw[8];
         std::memcpy(zw, z, 32);
-        hipError_t e = hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream);
+        std::memset(s.h_small, 0, 64 * 4);
+        hipError_t e = hipSuccess;
         PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
         launch_quotient(s.stream, s.d_stage, (uint32_t)len, zw, nullptr, sc);
         if (e == hipSuccess) e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream);
         if (e == hipSuccess) e = hipStreamSynchronize(s.stream);
         lk.lock();
         if (e != hipSuccess) {
@@ -1593,13 +1586,12 @@ int kzg_quotient(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t 
     int rc = ensure_poly(ctx, s, n);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(s.d_stage, coeffs, n * 32, hipMemcpyHostToDevice, s.stream));
-    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    std::memset(s.h_small, 0, 64 * 4);
     uint32_t zw[8];
     std::memcpy(zw, z, 32);
     PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
     launch_quotient(s.stream, s.d_stage, (uint32_t)n, zw, n > 1 ? s.d_q : nullptr, sc);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
     bool higher_nonzero = s.h_small[0] & 1u;
     if (!higher_nonzero) return std::memcmp(coeffs, y, 32) == 0 ? KZG_OK : KZG_ERR_CONSTANT_POLY;
@@ -1631,13 +1623,12 @@ int kzg_evaluate(kzg_ctx* ctx, const uint64_t* coeffs, size_t n, const uint64_t 
     int rc = ensure_poly(ctx, s, n);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(s.d_stage, coeffs, n * 32, hipMemcpyHostToDevice, s.stream));
-    HIP_TRY(ctx, hipMemsetAsync(s.d_small, 0, 64 * 4, s.stream));
+    std::memset(s.h_small, 0, 64 * 4);
     uint32_t zw[8];
     std::memcpy(zw, z, 32);
     PolyScratch sc{s.d_chunk, s.d_block, s.d_small, s.d_small + 8};
     launch_quotient(s.stream, s.d_stage, (uint32_t)n, zw, nullptr, sc);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipMemcpyAsync(s.h_small, s.d_small, 64 * 4, hipMemcpyDeviceToHost, s.stream));
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
     std::memcpy(out_y, s.h_small + 8, 32);
     return KZG_OK;

@@ -20,7 +20,10 @@
 
 namespace kzg {
 
-constexpr int kAccumBlock = 256;
+#ifndef KZG_ACCUM_BLOCK
+#define KZG_ACCUM_BLOCK 256
+#endif
+constexpr int kAccumBlock = KZG_ACCUM_BLOCK;  // lanes per workgroup; the lanes never synchronise (the prefetch slots are per wave)
 
 // table record (engine.h): x digits in words 0..12, y digits in words 16..28 of a 128-byte line
 __device__ __forceinline__ Fq load_fq(const uint4* __restrict__ p) {
@@ -511,6 +514,7 @@ void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t
     }
     // dynamic LDS: the prefetch slots (8 KiB per wave), or more when the caller reserves LDS to shape occupancy
     const uint32_t need = (kAccumBlock / 64) * 8 * 64 * 16;
+    lds_reserve_bytes = lds_reserve_bytes / (256 / kAccumBlock);  // the caller's reservation is per 256 lanes
     if (lds_reserve_bytes < need) lds_reserve_bytes = need;
     hipLaunchKernelGGL(k_bucket_accumulate, dim3(lanes / kAccumBlock), dim3(kAccumBlock), lds_reserve_bytes, s,
                        reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb, lanes,

@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_chunks(const uint32_t* __re
         if (((uint64_t)t * kPolyL + k) >= 1 && !c.is_zero()) nz = true;  // (coefficients past n were staged as zero)
         h = fe_add(fe_mul(h, z), c);
     }
-    if (__any(nz) && lane == 0) atomicOr(&d_flags[0], 1u);
+    if (__any(nz) && lane == 0) d_flags[0] = 1u;  // (the flag words are host-mapped: plain stores, every writer stores 1)
     if (t == 0) store_fr(d_flags + 16, poly_lds_coeff(lds_wave, 0, 0));  // c[0]
     h = block_suffix_scan<kPolyBlock>(h, pw.zl_sq, lds);
     store_fr(d_chunk + (size_t)t * 8, h);

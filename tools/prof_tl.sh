@@ -4,7 +4,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -rf gpurun_out/prof_tl
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_tl -- python3 bench.py --no-cpu-baseline --steps 16 --warmup 3 > gpurun_out/prof_tl.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_tl -- python3 bench.py --no-cpu-baseline --no-extras --steps 16 --warmup 3 > gpurun_out/prof_tl.log 2>&1 || exit 1
 f=$(ls -t $(find gpurun_out/prof_tl -name "*kernel_trace.csv") | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
