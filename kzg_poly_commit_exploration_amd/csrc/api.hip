@@ -38,7 +38,13 @@ namespace {
 // with 32 bits, so the C-ABI refuses them too instead of truncating the count.
 constexpr size_t kMaxCoefficients = 0xFFFFFFFFull;
 
-constexpr int kNumSlots = 3;  // + the shared accumulation stream = the 4 hardware queues HIP gives a process by default
+// Stream slots per context (+ the shared accumulation stream: 6 of the 8 hardware queues the library asks for).  The
+// light kernels of a job -- sort in front of its accumulation, finalisation and reduction trees behind it -- only get
+// the chip in the tail of ANOTHER job's accumulation and crawl while one is running (round-3 timeline: a 54 us sort
+// kernel takes 260, the trees 1 ms).  With three jobs in flight the next job's sort regularly finished 100-240 us after
+// the accumulation it should have hidden under; five give it one more accumulation's worth of time: 366 -> 389
+// commitments/s on the same box (4: 383-390, 6: 381-385, 7: 368-385).
+constexpr int kNumSlots = 5;
 // Reduction plan (msm_reduce.hip): bucket index b = hi * C + lo; Row (R entries) and Col (C entries)
 // are each split once more into a "row" part and a "column" part that the host receives.
 struct ReducePlan {

@@ -486,7 +486,7 @@ def test_concurrent_host_threads_share_one_context(engines, oracle, golden):
 
 def test_host_pointer_callers_overlap_on_the_stream_slots(engines, oracle, golden):
     """kzg_commit from four host threads at degree 2^20: the calls hold the context mutex only while they touch the
-    slot table, so their jobs occupy the three slots and pipeline (sort and reduction of one in the shadow of another's
+    slot table, so their jobs occupy stream slots of their own and pipeline (sort and reduction of one in the shadow of another's
     accumulation, uploads beside kernels).  Wall time of 4 x 6 threaded calls must be below 24 serial ones (measured:
     0.72-0.76 of it; the bound leaves room for a noisy box -- the rates themselves are bench.py's business)."""
     import threading
