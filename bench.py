@@ -299,10 +299,12 @@ def main():
     n_mine = hi - lo
     slots = eng.num_slots() if args.slots <= 0 else min(args.slots, eng.num_slots())
     cfg = eng.msm_config()
-    # The kernel's duration is measured LIVE, inside the timed region, with HIP events on the stream it runs on -- on
-    # every TIME_EVERY-th step only: a timed job records six events, two of them between consecutive accumulation
-    # kernels on their shared stream, and with every job timed that instrumentation alone cost 8-10 % of the rate it
-    # was there to explain (356-364 against 392-395 commitments/s on one box, profiles/r03_timing_overhead.txt).
+    # The kernel's duration is measured LIVE, inside the timed region, for EVERY step: the accumulation kernel stamps
+    # its own first wave in and last wave out on the device's 100 MHz clock (what rocprofv3 --kernel-trace reports).
+    # HIP events on the stream it runs on bracket it on every TIME_EVERY-th step only: a timed job records six events,
+    # two of them between consecutive accumulation kernels on their shared stream, and with every job timed that
+    # instrumentation alone cost 8-10 % of the rate it was there to explain (356-364 against 392-395 commitments/s on
+    # one box, profiles/r03_timing_overhead.txt).
     TIME_EVERY = max(1, int(os.environ.get("KZG_BENCH_TIME_EVERY", "5")))
 
     results = []
@@ -312,11 +314,13 @@ def main():
 
     def collect(slot):
         partials = eng.wait_batch(slot, batch)
+        t = eng.times(slot)
+        accum_ms.append(t["accumulate_ms"])          # every step: the kernel's own stamps, no event involved
+        phase_ms.setdefault("references", []).append(t["references"])
         if timed_slot.get(slot):
-            t = eng.times(slot)
-            accum_ms.append(t["accumulate_ms"])
             for k, v in t.items():
-                phase_ms.setdefault(k, []).append(v)
+                if k != "references":
+                    phase_ms.setdefault(k, []).append(v)
         if dist is not None:
             partials = [combine(ps) for ps in allgather_partial_batch(partials, device=xdev)]
         results.extend(partials)
@@ -449,6 +453,13 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": ("offline: profiles/r03_traffic.json, same kernel sources" if traffic else None),
                          "kernel": "k_bucket_accumulate", "avg_kernel_ms": avg_accum_ms,
+                         "avg_kernel_ms_hip_event_bracket": (sum(phase_ms.get("accumulate_events_ms", [0.0])) /
+                                                             max(1, len(phase_ms.get("accumulate_events_ms", [])))),
+                         "timing": "avg_kernel_ms: every step of the timed region, the kernel's own duration (first wave in to last wave "
+                                   "out, stamped by the kernel on the device's 100 MHz clock: what rocprofv3 --kernel-trace reports); "
+                                   "avg_kernel_ms_hip_event_bracket: HIP events on its stream around every %d-th step (six events per "
+                                   "timed job cost the pipeline 8-10 %% when every job carried them), which also hold the time the "
+                                   "launch waited for the chip" % TIME_EVERY,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "kernel_source_hash": kernel_source_hash(),
                          "note": "integer/modular work with no MFMA form: the kernel is bound by VALU issue (see valu), "

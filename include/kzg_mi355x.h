@@ -36,9 +36,9 @@ extern "C" {
 typedef struct kzg_ctx kzg_ctx;
 
 /* Bumped whenever a struct or a signature below changes incompatibly (2: kzg_kernel_times lost `scan_ms` in round 2;
- * 3: kzg_ctx_create_multi_ex, host-pointer batches).  kzg_abi_version() returns the value the library was built
+ * 3: kzg_ctx_create_multi_ex, host-pointer batches; 4: kzg_kernel_times gained accumulate_events_ms at its end).  kzg_abi_version() returns the value the library was built
  * with: a caller compiled against another value must not read kzg_kernel_times. */
-#define KZG_ABI_VERSION 3
+#define KZG_ABI_VERSION 4
 int kzg_abi_version(void);
 
 typedef enum kzg_status {
@@ -251,15 +251,19 @@ int kzg_verify_proof_batch(const uint64_t* commitments_p1, const uint64_t* proof
 /* ---- measurement -------------------------------------------------------------------------- */
 
 typedef struct kzg_kernel_times {
-    /* per-kernel HIP-event times of the most recent kzg_wait on the slot, milliseconds, measured on
-     * the stream the kernels ran on (only filled while timing is enabled) */
+    /* the most recent job collected from the slot.  accumulate_ms and references come from the device itself and are
+     * filled for EVERY job; the other fields are HIP-event spans on the streams the kernels ran on, in milliseconds,
+     * filled only for jobs submitted while timing was enabled (kzg_set_timing): a timed job records six events */
     float digits_ms;      /* scalar recoding + two-level counting sort (all of msm_sort.hip) */
     float scatter_ms;     /* queueing: buffer clears + the wait for the shared accumulation stream (not kernel cost) */
-    float accumulate_ms;  /* bucket accumulation: the dominant kernel, events on the stream it runs on */
+    float accumulate_ms;  /* bucket accumulation, the dominant kernel: its own duration, first wave in to last wave out on the
+                           * device's constant 100 MHz clock (the kernel stamps itself; no event sits between two launches) */
     float reduce_ms;      /* finalisation + reduction trees, INCLUDING their wait behind the next accumulation */
     float quotient_ms;    /* open only: scalar-field synthetic division */
     float total_ms;       /* first kernel start -> last kernel end */
     uint64_t references;  /* non-zero scalar digits = mixed additions of the accumulation kernel (whole batch) */
+    float accumulate_events_ms;  /* the HIP-event bracket around the same launch on its stream: kernel + the time it waited for the chip */
+    float reserved_;
 } kzg_kernel_times;
 
 int kzg_set_timing(kzg_ctx* ctx, int enabled);

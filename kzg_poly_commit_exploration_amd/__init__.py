@@ -35,7 +35,7 @@ KZG_ERR_HIP = -6
 KZG_ERR_NO_SRS = -7
 KZG_ERR_BUSY = -8
 KZG_MULTI_REPLICATE_SRS = 1
-KZG_ABI_VERSION = 3
+KZG_ABI_VERSION = 4
 
 # every symbol include/kzg_mi355x.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -62,7 +62,7 @@ class KzgError(Exception):
 class KernelTimes(C.Structure):
     _fields_ = [(n, C.c_float) for n in
                 ("digits_ms", "scatter_ms", "accumulate_ms", "reduce_ms", "quotient_ms", "total_ms")
-                ] + [("references", C.c_uint64)]
+                ] + [("references", C.c_uint64), ("accumulate_events_ms", C.c_float), ("reserved_", C.c_float)]
 
 
 def lib_path():

@@ -411,7 +411,8 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
         }
         if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 3], hs));
         launch_bucket_accumulate(hs, ctx->d_table, s.d_sorted, s.d_offs, nbt, lanes, s.d_buckets, s.d_part_a, s.d_part_b,
-                                 ctx->accum_lds_bytes, s.d_pair_scratch, max_refs);
+                                 ctx->accum_lds_bytes, s.d_pair_scratch, max_refs,
+                                 (char*)s.d_heavy_ws + kAccumClockOffset);
         if (s.timing) HIP_TRY(ctx, hipEventRecord(s.ev[ev_base + 4], hs));
         if (hand_over) {
             HIP_TRY(ctx, hipEventRecord(s.accum_ev, hs));
@@ -466,6 +467,24 @@ hf::P1 finish_msm(const kzg_ctx* ctx, const Slot& s, uint32_t p = 0, uint32_t ba
 }
 
 void write_p1(uint64_t out[18], const hf::P1& p) { std::memcpy(out, &p, sizeof p); }
+
+// EVERY job: accumulate_ms is the accumulation kernel's own duration -- first wave in to last wave out on the constant
+// 100 MHz clock, stamped by the kernel and passed on by the finalisation (h_small[28..31]; the one-launch path of
+// small jobs leaves it 0) -- and `references` its number of mixed additions: no stream event is involved.  Timed jobs
+// (kzg_set_timing) also get the HIP-event spans; accumulate_events_ms is the bracket around the same launch on its
+// stream, which holds the time the launch waited for the chip as well.
+void fill_device_times(Slot& s) {
+    s.times.references = s.h_small[26];
+    const uint64_t not_start = (uint64_t)s.h_small[28] | ((uint64_t)s.h_small[29] << 32);
+    const uint64_t end = (uint64_t)s.h_small[30] | ((uint64_t)s.h_small[31] << 32);
+    if (not_start != 0 && end > ~not_start) s.times.accumulate_ms = (float)((double)(end - ~not_start) * 1e-5);  // 10 ns ticks
+}
+void fill_accumulate_times(Slot& s) {  // timed jobs, after fill_device_times
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, s.ev[3], s.ev[4]);
+    s.times.accumulate_events_ms = ms;
+    if (s.times.accumulate_ms == 0) s.times.accumulate_ms = ms;
+}
 
 // ---- slot ownership of the synchronous host-pointer entry points (all of these with ctx->mu held) ------------------
 void slot_idle(kzg_ctx* ctx, Slot& s) {
@@ -1040,13 +1059,13 @@ static int wait_locked(kzg_ctx* ctx, int slot, uint64_t out_p1[18]) {
     SlotKind kind = s.kind;
     slot_idle(ctx, s);
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    if (kind != SLOT_TRIVIAL) fill_device_times(s);
     if (s.timing && kind != SLOT_TRIVIAL) {
         float ms = 0;
         hipEventElapsedTime(&ms, s.ev[0], s.ev[1]); s.times.digits_ms = ms;
         hipEventElapsedTime(&ms, s.ev[2], s.ev[3]); s.times.scatter_ms = ms;
-        hipEventElapsedTime(&ms, s.ev[3], s.ev[4]); s.times.accumulate_ms = ms;
+        fill_accumulate_times(s);
         hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;
-        s.times.references = s.h_small[26];
         if (s.has_quotient) {
             hipEventElapsedTime(&ms, s.ev[6], s.ev[7]); s.times.quotient_ms = ms;
             hipEventElapsedTime(&ms, s.ev[6], s.ev[5]); s.times.total_ms = ms;
@@ -1153,13 +1172,13 @@ static int wait_batch_locked(kzg_ctx* ctx, int slot, uint64_t* out_p1s, size_t b
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     slot_idle(ctx, s);
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    fill_device_times(s);
     if (s.timing) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, s.ev[0], s.ev[1]); s.times.digits_ms = ms;
         (void)hipEventElapsedTime(&ms, s.ev[2], s.ev[3]); s.times.scatter_ms = ms;
-        (void)hipEventElapsedTime(&ms, s.ev[3], s.ev[4]); s.times.accumulate_ms = ms;
+        fill_accumulate_times(s);
         (void)hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;
-        s.times.references = s.h_small[26];
         (void)hipEventElapsedTime(&ms, s.ev[0], s.ev[5]); s.times.total_ms = ms;
     }
     // host tails of the batch in parallel (each is ~150 point operations and one inversion)
@@ -1252,13 +1271,13 @@ static int wait_open_batch_locked(kzg_ctx* ctx, int slot, uint64_t* out_p1s, int
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     slot_idle(ctx, s);
     HIP_TRY(ctx, hipStreamSynchronize(s.stream));
+    fill_device_times(s);
     if (s.timing) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, s.ev[6], s.ev[7]); s.times.quotient_ms = ms;
         (void)hipEventElapsedTime(&ms, s.ev[0], s.ev[1]); s.times.digits_ms = ms;
-        (void)hipEventElapsedTime(&ms, s.ev[3], s.ev[4]); s.times.accumulate_ms = ms;
+        fill_accumulate_times(s);
         (void)hipEventElapsedTime(&ms, s.ev[4], s.ev[5]); s.times.reduce_ms = ms;
-        s.times.references = s.h_small[26];
         (void)hipEventElapsedTime(&ms, s.ev[6], s.ev[5]); s.times.total_ms = ms;
     }
     const uint32_t B = s.job_batch;

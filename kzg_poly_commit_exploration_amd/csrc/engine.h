@@ -82,7 +82,10 @@ size_t accumulate_pair_scratch_bytes(uint64_t max_refs);
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
                               uint32_t nb, uint32_t lanes, void* d_buckets /* complete buckets only: the rest by the finalisation */,
                               void* d_part_a, void* d_part_b, uint32_t lds_reserve_bytes, void* d_pair_scratch,
-                              uint64_t max_refs);
+                              uint64_t max_refs, void* d_clock = nullptr /* kAccumClockOffset into the job's zeroed header, or null */);
+// the accumulation kernel's own start / end stamps: two u64 in the job header (zeroed by the sort), copied next to the
+// reference count by the finalisation (d_refs_out[2..5])
+constexpr size_t kAccumClockOffset = 768;  // bytes into d_heavy_ws (words 192..195 of the header: unused by the counters)
 // adds the head / tail partials of buckets that span several segments (serial for short runs, three passes of
 // 64-wide trees for long ones) and writes empty buckets as infinity: every bucket is written once per job, the array is
 // never cleared.  d_heavy_ws: heavy_workspace_bytes() of scratch whose first kHeavyHeaderBytes (the counters) are zero

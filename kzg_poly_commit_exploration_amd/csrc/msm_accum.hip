@@ -72,7 +72,13 @@ __global__ void KZG_ACCUM_ATTR __launch_bounds__(kAccumBlock, KZG_ACCUM_MIN_BLOC
                                                                   const uint32_t* __restrict__ offs, uint32_t nb,
                                                                   uint32_t lanes, uint4* __restrict__ buckets,
                                                                   uint4* __restrict__ part_a,
-                                                                  uint4* __restrict__ part_b) {
+                                                                  uint4* __restrict__ part_b,
+                                                                  unsigned long long* __restrict__ clk) {
+    // clk (may be null): two zeroed words that receive max(~start) and max(end) over the waves of the launch, in ticks
+    // of the constant 100 MHz clock -- the kernel's own duration, measured without a stream event on either side of it
+    // (events between consecutive accumulation kernels cost the pipeline 8-10 %)
+    const bool stamp = clk != nullptr && (threadIdx.x & 63) == 0;
+    if (stamp) atomicMax(&clk[0], ~(unsigned long long)wall_clock64());
     const uint32_t lane = blockIdx.x * kAccumBlock + threadIdx.x;
     const uint32_t M = offs[nb];
     const uint32_t L = accumulate_seg_len(M, lanes);
@@ -158,6 +164,7 @@ __global__ void KZG_ACCUM_ATTR __launch_bounds__(kAccumBlock, KZG_ACCUM_MIN_BLOC
     else if (run_start == start) dst = part_a + (size_t)lane * kXyzzU4;            // covers the whole segment
     else dst = part_b + (size_t)lane * kXyzzU4;                                    // tail shared with the next lane
     store_xyzz30(dst, acc);
+    if (stamp) atomicMax(&clk[1], (unsigned long long)wall_clock64());
 }
 
 // ---- the same with an affine front end -----------------------------------------------------------------------------
@@ -502,7 +509,7 @@ size_t accumulate_pair_scratch_bytes(uint64_t max_refs) {
 
 void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t* d_sorted, const uint32_t* d_offs,
                               uint32_t nb, uint32_t lanes, void* d_buckets, void* d_part_a, void* d_part_b,
-                              uint32_t lds_reserve_bytes, void* d_pair_scratch, uint64_t max_refs) {
+                              uint32_t lds_reserve_bytes, void* d_pair_scratch, uint64_t max_refs, void* d_clock) {
     if (!lanes) return;
     if (accumulate_pairs_enabled() && d_pair_scratch && max_refs / lanes >= 16) {
         hipLaunchKernelGGL(k_bucket_accumulate_pairs, dim3(lanes / kAccumBlock), dim3(kAccumBlock),
@@ -519,7 +526,7 @@ void launch_bucket_accumulate(hipStream_t s, const void* d_table, const uint32_t
     hipLaunchKernelGGL(k_bucket_accumulate, dim3(lanes / kAccumBlock), dim3(kAccumBlock), lds_reserve_bytes, s,
                        reinterpret_cast<const uint4*>(d_table), d_sorted, d_offs, nb, lanes,
                        reinterpret_cast<uint4*>(d_buckets), reinterpret_cast<uint4*>(d_part_a),
-                       reinterpret_cast<uint4*>(d_part_b));
+                       reinterpret_cast<uint4*>(d_part_b), reinterpret_cast<unsigned long long*>(d_clock));
 }
 
 }  // namespace kzg

@@ -86,7 +86,11 @@ __global__ void __launch_bounds__(64 * kCoop, KZG_TREE_WAVES) k_bucket_finalize(
                                                         uint32_t* __restrict__ refs_out) {
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / kCoop;  // one quad per bucket
     const bool lead = (threadIdx.x & 3u) == 0;
-    if (b == 0 && lead && refs_out) refs_out[0] = offs[nb];  // number of references, for the host's statistics
+    if (b == 0 && lead && refs_out) {
+        refs_out[0] = offs[nb];  // number of references, for the host's statistics
+#pragma unroll
+        for (int i = 0; i < 4; i++) refs_out[2 + i] = ws.counters[kAccumClockOffset / 4 + i];  // the accumulation's start / end stamps
+    }
     if (b >= nb) return;
     const uint32_t L = accumulate_seg_len(offs[nb], lanes);
     uint32_t s = offs[b], e = offs[b + 1];
@@ -165,7 +169,11 @@ __global__ void __launch_bounds__(64 * kCoop, KZG_TREE_WAVES) k_bucket_finalize_
     const bool lead = (threadIdx.x & 3u) == 0;
     const uint32_t b = blockIdx.x * (64 / group) + t / group;
     const uint32_t l = t & (group - 1);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && refs_out) refs_out[0] = offs[nb];
+    if (blockIdx.x == 0 && threadIdx.x == 0 && refs_out) {
+        refs_out[0] = offs[nb];
+#pragma unroll
+        for (int i = 0; i < 4; i++) refs_out[2 + i] = ws.counters[kAccumClockOffset / 4 + i];
+    }
     // every thread reaches the barriers below: inactive groups carry infinity through them
     uint32_t span = 0, l_lo = 0;
     bool first_is_b = false;

@@ -28,6 +28,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_abi_version_and_struct_mirrors():
+    lib = K.load_library()
+    assert lib.kzg_abi_version() == K.KZG_ABI_VERSION == 4
+    text = open(os.path.join(ROOT, "include", "kzg_mi355x.h")).read()
+    assert "#define KZG_ABI_VERSION 4" in text
+    # kzg_kernel_times: six floats, a u64, two floats (the Python mirror must have the C layout)
+    assert C.sizeof(K.KernelTimes) == 40
+
+
 def test_strerror_carries_reference_messages():
     lib = K.load_library()
     # reference src/polynomial.rs:202-204, :165, :189-191
