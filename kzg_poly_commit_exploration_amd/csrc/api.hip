@@ -321,8 +321,6 @@ int build_tables(kzg_ctx* ctx, hipStream_t st, void* d_xyzz_tmp, void* d_prefix)
         char* next = (char*)ctx->d_table + (size_t)j * n * kAffineBytes;
         launch_table_window(st, prev, (uint32_t)n, ctx->cfg.level_bits, d_xyzz_tmp, d_prefix, next);
     }
-    // every level is complete: rewrite the records into the accumulation kernel's native field representation
-    launch_table_to_fq(st, ctx->d_table, (uint64_t)ctx->cfg.W * n);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(st));
     return KZG_OK;
@@ -686,7 +684,7 @@ int kzg_srs_load_g1(kzg_ctx* ctx, const void* first_g1, size_t stride, size_t n)
     for (size_t i = 0; i < n; i++) std::memcpy(&packed[i * 18], (const char*)first_g1 + i * stride, 144);
     DevBuf d_jac, d_prefix, d_xyzz;
     HIP_TRY(ctx, hipMalloc(&d_jac.p, n * 144));
-    HIP_TRY(ctx, hipMalloc(&d_prefix.p, n * 48));
+    HIP_TRY(ctx, hipMalloc(&d_prefix.p, n * 64));
     HIP_TRY(ctx, hipMalloc(&d_xyzz.p, n * kXyzzBytes));
     TmpStream st;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
@@ -722,7 +720,7 @@ int kzg_srs_generate_g1(kzg_ctx* ctx, const uint8_t secret_be[32], uint64_t firs
     size_t tmp_records = n > 32 * 255 ? n : 32 * 255;
     DevBuf d_gtable, d_prefix, d_xyzz;
     HIP_TRY(ctx, hipMalloc(&d_gtable.p, srs_gtable_bytes()));
-    HIP_TRY(ctx, hipMalloc(&d_prefix.p, tmp_records * 48));
+    HIP_TRY(ctx, hipMalloc(&d_prefix.p, tmp_records * 64));
     HIP_TRY(ctx, hipMalloc(&d_xyzz.p, tmp_records * kXyzzBytes));
     TmpStream st;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&st.s, hipStreamNonBlocking));
@@ -739,7 +737,7 @@ int kzg_srs_generate_g1(kzg_ctx* ctx, const uint8_t secret_be[32], uint64_t firs
 // level 0 is in d_table (builder's form): build the other levels, convert, size the slots
 static int finish_srs_from_level0(kzg_ctx* ctx, hipStream_t st, size_t n) {
     DevBuf d_prefix, d_xyzz;
-    HIP_TRY(ctx, hipMalloc(&d_prefix.p, n * 48));
+    HIP_TRY(ctx, hipMalloc(&d_prefix.p, n * 64));
     HIP_TRY(ctx, hipMalloc(&d_xyzz.p, n * kXyzzBytes));
     ctx->n = n;
     int rc = build_tables(ctx, st, d_xyzz.p, d_prefix.p);

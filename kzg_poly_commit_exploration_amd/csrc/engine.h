@@ -7,10 +7,9 @@
 
 namespace kzg {
 
-// One affine SRS / table point in HBM: x then y, 12 + 12 little-endian u32 limbs, Montgomery
-// (96 bytes of payload), (0,0) = infinity, padded to a 128-byte record so that every random gather of
-// the accumulation kernel touches exactly one 128-byte line (at 96 B a record straddles 1.5 lines on
-// average and the kernel fetched 2x its payload; PMC figures in DESIGN.md).  Table layout:
+// One affine SRS / table point in HBM: x as 13 signed radix-2^30 digits in words 0..12, y in words 16..28
+// (field30.hip.h: Montgomery R' = 2^390, magnitude < 0.62 p), all zero = infinity: a 128-byte record, so that every
+// random gather of the accumulation kernel touches exactly one 128-byte line.  Table layout:
 // level-major, T[j * n + i] = 2^(level_bits*j) * SRS[i]  (j < W), so level 0 is the SRS itself.
 constexpr size_t kAffineBytes = 128;
 constexpr size_t kAffineU4 = kAffineBytes / 16;  // record stride in uint4 units
@@ -137,16 +136,13 @@ void launch_srs_generate(hipStream_t s, const uint32_t* secret_raw8 /* 256-bit L
                          void* d_gtable, void* d_xyzz_tmp, void* d_prefix_tmp, void* d_affine_out);
 size_t srs_gtable_bytes();
 // ---- srs_io.hip ------------------------------------------------------------------------
-// n x 96-byte affine points (x, y as blst_fp; (0, 0) = infinity) -> table level 0 (builder's form)
+// n x 96-byte affine points (x, y as blst_fp; (0, 0) = infinity) -> table level 0
 void launch_affine96_to_table(hipStream_t s, const void* d_affine96, uint32_t n, void* d_table);
 // n x 48-byte compressed points (ZCash encoding) -> table level 0; *d_status (pre-set to 0xffffffff) receives
 // index + 1 of the first malformed point
 void launch_uncompress(hipStream_t s, const void* d_compressed, uint32_t n, void* d_table, uint32_t* d_status);
 
 // ---- msm_accum.hip (table format) ---------------------------------------------------------
-// rewrites `records` finished table records in place from the builder's 12 x u32 form into the accumulation kernel's
-// native form (13 signed radix-2^30 digits per coordinate, x in words 0..12, y in words 16..28 of the 128-B record)
-void launch_table_to_fq(hipStream_t s, void* d_table, uint64_t records);
 // native table entries -> blst_p1 (Z = Montgomery one / all zero for infinity)
 void launch_affine_to_p1(hipStream_t s, const void* d_affine, uint32_t n, void* d_p1_out);
 

@@ -406,37 +406,6 @@ __global__ void __launch_bounds__(kAccumBlock, 2) k_bucket_accumulate_pairs(cons
 }
 
 // ---- table format -------------------------------------------------------------------------------------------------
-// srs_kernels.hip builds the window table with the 12 x u32 field (x | y, 96 B of a 128-B record).  Once it is
-// complete every record is rewritten in place into the accumulation kernel's native form: 13 signed radix-2^30
-// digits of x * 2^390 reduced below 0.62 p, x in words 0..12 and y in words 16..28.  (0, 0) stays all zero.
-__global__ void __launch_bounds__(256) k_table_to_fq(uint4* __restrict__ table, uint64_t count) {
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
-    uint4* rec = table + i * kAffineU4;
-    uint32_t w[24];
-#pragma unroll
-    for (int t = 0; t < 6; t++) {
-        const uint4 v = rec[t];
-        w[4 * t] = v.x; w[4 * t + 1] = v.y; w[4 * t + 2] = v.z; w[4 * t + 3] = v.w;
-    }
-    uint32_t any = 0;
-#pragma unroll
-    for (int t = 0; t < 24; t++) any |= w[t];
-    uint32_t o[32];
-#pragma unroll
-    for (int t = 0; t < 32; t++) o[t] = 0;
-    if (any) {
-        const Fq x = fq_mul(fq_from_u32x12(w), fq_one());       // 64 s reduced: same residue, magnitude < 0.62 p
-        const Fq y = fq_mul(fq_from_u32x12(w + 12), fq_one());
-#pragma unroll
-        for (int t = 0; t < kQ; t++) {
-            o[t] = (uint32_t)x.d[t];
-            o[16 + t] = (uint32_t)y.d[t];
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < 8; t++) rec[t] = make_uint4(o[4 * t], o[4 * t + 1], o[4 * t + 2], o[4 * t + 3]);
-}
 // native records -> blst_p1 (canonical 12 x u32 Montgomery R = 2^384 limbs, Z = one or zero): kzg_srs_read_g1
 __global__ void __launch_bounds__(64) k_fq_table_to_p1(const uint4* __restrict__ table, uint32_t n, uint4* __restrict__ out) {
     const uint32_t i = blockIdx.x * 64 + threadIdx.x;
@@ -456,10 +425,6 @@ __global__ void __launch_bounds__(64) k_fq_table_to_p1(const uint4* __restrict__
     uint4* o = out + (size_t)i * 9;
 #pragma unroll
     for (int t = 0; t < 9; t++) o[t] = make_uint4(w[4 * t], w[4 * t + 1], w[4 * t + 2], w[4 * t + 3]);
-}
-void launch_table_to_fq(hipStream_t s, void* d_table, uint64_t records) {
-    if (!records) return;
-    hipLaunchKernelGGL(k_table_to_fq, dim3((unsigned)((records + 255) / 256)), dim3(256), 0, s, (uint4*)d_table, records);
 }
 void launch_affine_to_p1(hipStream_t s, const void* d_affine, uint32_t n, void* d_p1) {
     if (!n) return;

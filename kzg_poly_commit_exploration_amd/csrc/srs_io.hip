@@ -3,23 +3,45 @@
 //  * compressed points (48 bytes, ZCash encoding: reference src/curves.rs:99-183, the strings of the CLI's
 //    setup.json): every lane decompresses one point, y = (x^3 + 4)^((p+1)/4) with the sign bit of the encoding,
 //    instead of one blst_p1_uncompress per point on the host.
-// Both write table level 0 in the builder's 12 x u32 form (srs_kernels.hip builds the other levels from it).
+// Both write table level 0 in the table's own record form (x digits in words 0..12, y digits in words 16..28 of a 128-byte
+// record, all zero = infinity); srs_kernels.hip builds the other levels from it.
 #include "engine.h"
 #include "field30.hip.h"
 
 namespace kzg {
 
-// 96-byte affine records -> 128-byte table records (x | y | padding), (0, 0) = infinity as in the table
+__device__ __forceinline__ void store_digits16(uint4* __restrict__ p, const Fq& a) {
+    p[0] = make_uint4((uint32_t)a.d[0], (uint32_t)a.d[1], (uint32_t)a.d[2], (uint32_t)a.d[3]);
+    p[1] = make_uint4((uint32_t)a.d[4], (uint32_t)a.d[5], (uint32_t)a.d[6], (uint32_t)a.d[7]);
+    p[2] = make_uint4((uint32_t)a.d[8], (uint32_t)a.d[9], (uint32_t)a.d[10], (uint32_t)a.d[11]);
+    p[3] = make_uint4((uint32_t)a.d[12], 0u, 0u, 0u);
+}
+
+// 96-byte affine records (x, y as blst_fp: 12 x u32, Montgomery R = 2^384) -> 128-byte table records; (0, 0) = infinity
 __global__ void __launch_bounds__(256) k_affine96_to_table(const uint4* __restrict__ in, uint32_t n, uint4* __restrict__ table) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint4* src = in + (size_t)i * 6;
     uint4* dst = table + (size_t)i * kAffineU4;
-    const uint4 zero = make_uint4(0, 0, 0, 0);
+    uint32_t w[24];
 #pragma unroll
-    for (int t = 0; t < 6; t++) dst[t] = src[t];
-    dst[6] = zero;
-    dst[7] = zero;
+    for (int t = 0; t < 6; t++) {
+        const uint4 v = src[t];
+        w[4 * t] = v.x; w[4 * t + 1] = v.y; w[4 * t + 2] = v.z; w[4 * t + 3] = v.w;
+    }
+    uint32_t any = 0;
+#pragma unroll
+    for (int t = 0; t < 24; t++) any |= w[t];
+    if (!any) {
+        const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 8; t++) dst[t] = zero;
+        return;
+    }
+    // stored s = x * 2^384; the signed form wants x * 2^390 = 64 s: the same bits six places higher, then one product
+    // with the Montgomery one to bring the magnitude below 0.62 p
+    store_digits16(dst, fq_mul(fq_from_u32x12(w), fq_one()));
+    store_digits16(dst + 4, fq_mul(fq_from_u32x12(w + 12), fq_one()));
 }
 
 KZG_HD Fq fq_const_2_780() {
@@ -150,13 +172,8 @@ __global__ void __launch_bounds__(64) k_uncompress(const uint8_t* __restrict__ i
     const Fq yi = fq_canonical_integer(y);
     const bool is_big = fq_digits_greater(yi, fq_const_half());
     if (is_big != y_big) y = fq_neg(y);
-    uint32_t o[24];
-    fq_to_u32x12(x, o);
-    fq_to_u32x12(y, o + 12);
-#pragma unroll
-    for (int k = 0; k < 6; k++) dst[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
-    dst[6] = zero;
-    dst[7] = zero;
+    store_digits16(dst, x);
+    store_digits16(dst + 4, fq_norm(y));  // (the negation keeps the digits' size; one carry pass for the table's contract)
     if (bad) atomicMin(status, i + 1);
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Regenerates the hand-scheduled v_mad_u64_u32 / v_addc_co_u32 groups at the top of csrc/field_fips.hip.h
+"""Regenerates the hand-scheduled v_mad_u64_u32 / v_addc_co_u32 groups at the top of tools/legacy_field/field_fips.hip.h
 (macc{1..6}_vv, macc{1..6}_vv_first, macc{1..6}_vs).
 
 Schedule: N multiply-adds into one 64-bit accumulator pair, each writing its carry to one of three SGPR pairs
@@ -78,7 +78,7 @@ def asm_strings(text):
 if __name__ == "__main__":
     if "--check" in sys.argv:
         here = os.path.dirname(os.path.abspath(__file__))
-        hdr = open(os.path.join(here, "..", "kzg_poly_commit_exploration_amd", "csrc", "field_fips.hip.h")).read()
+        hdr = open(os.path.join(here, "legacy_field", "field_fips.hip.h")).read()
         have = dict(asm_strings(hdr))
         want = dict(asm_strings("\n".join(all_functions())))
         bad = [k for k in want if have.get(k) != want[k]]

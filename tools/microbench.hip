@@ -9,7 +9,7 @@
 
 #include <vector>
 
-#include "../kzg_poly_commit_exploration_amd/csrc/g1.hip.h"
+#include "legacy_field/g1.hip.h"  // rounds 1-2: the 12 x u32 field, kept for the comparisons
 #include "../kzg_poly_commit_exploration_amd/csrc/g1_30.hip.h"
 
 using namespace kzg;
