@@ -188,6 +188,10 @@ KZG_DEV void for_each_digit(u32 k[8], MsmConfig cfg, F&& f) {
 // No global atomics, no rank array; order inside a bucket is arbitrary (the group law is commutative,
 // the result is bit-identical).
 constexpr int kSortBlock = 256;
+// The two recoding passes run 1024 lanes per workgroup: a tile is one workgroup (at most 256 tiles bound the offset table),
+// and with 256 lanes a CU held ONE wave per SIMD walking 16 scalars one after the other -- load, from-Montgomery
+// product, 15 LDS atomics -- with nothing to hide the loads behind (54 + 85 us at 2^20).
+constexpr int kRecodeBlock = 1024;
 constexpr int kMaxCoarse = 2048;
 constexpr int kFineMax = 256;
 
@@ -237,18 +241,18 @@ struct BatchGeom {
     uint32_t nb;      // buckets per polynomial
 };
 
-__global__ void __launch_bounds__(kSortBlock) k_sort_count(const uint32_t* __restrict__ d_scalars, int is_mont,
+__global__ void __launch_bounds__(kRecodeBlock) k_sort_count(const uint32_t* __restrict__ d_scalars, int is_mont,
                                                            BatchGeom bg, MsmConfig cfg, uint32_t tile,
                                                            uint32_t fine_bits, uint32_t coarse_bins,
                                                            uint32_t* __restrict__ d_cnt, uint32_t* __restrict__ d_binfill /* zero */,
                                                            uint32_t* __restrict__ d_header) {
     __shared__ u32 s_hist[kMaxCoarse];
     if (blockIdx.x == 0 && threadIdx.x < kHeavyHeaderBytes / 4) d_header[threadIdx.x] = 0;  // the job's counters (one stream operation fewer per job)
-    for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) s_hist[q] = 0;
+    for (uint32_t q = threadIdx.x; q < coarse_bins; q += kRecodeBlock) s_hist[q] = 0;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * tile;
     const uint64_t total = (uint64_t)bg.n * bg.batch;
-    for (uint32_t off = threadIdx.x; off < tile; off += kSortBlock) {
+    for (uint32_t off = threadIdx.x; off < tile; off += kRecodeBlock) {
         uint64_t g = base + off;
         if (g >= total) break;
         uint32_t p = (uint32_t)(g / bg.n);
@@ -263,13 +267,15 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_count(const uint32_t* __res
     // returning where the tile's pairs of that bin start): the bin fill counters end up holding the bin totals, and no
     // kernel has to add up the count table afterwards.  Which tile comes first inside a bin is whatever order the
     // atomics arrive in -- the order of the references of one bucket is arbitrary anyway.
-    for (uint32_t q = threadIdx.x; q < coarse_bins; q += kSortBlock) {
+    for (uint32_t q = threadIdx.x; q < coarse_bins; q += kRecodeBlock) {
         const u32 c = s_hist[q];
         d_cnt[(size_t)blockIdx.x * coarse_bins + q] = c ? atomicAdd(&d_binfill[q], c) : 0u;  // [tile][bin]
     }
 }
 
-// exclusive scan of 256 values, one per thread, through LDS (Hillis-Steele); total of all of them in `total`
+// exclusive scan of N values, one per thread of an N-lane workgroup, through LDS (Hillis-Steele); their total in `total`
+template <int N>
+__device__ __forceinline__ u32 block_exclusive_scan_n(u32 v, u32* lds, u32& total);
 __device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* lds, u32& total);
 
 // pairs per chunk of the fine passes, and the workspace they share (u32 words)
@@ -282,7 +288,7 @@ constexpr uint32_t kWsTable = 3 * kMaxCoarse + 64;   // H
 uint32_t sort_workspace_words() { return kWsTable + kFineMaxChunks * (uint32_t)kFineMax + 64; }
 uint32_t sort_workspace_zero_words() { return kWsTable; }  // what the owner clears once, when it allocates the workspace
 
-__global__ void __launch_bounds__(kSortBlock) k_sort_spread(const uint32_t* __restrict__ d_scalars, int is_mont,
+__global__ void __launch_bounds__(kRecodeBlock) k_sort_spread(const uint32_t* __restrict__ d_scalars, int is_mont,
                                                             BatchGeom bg, uint32_t table_stride, MsmConfig cfg,
                                                             uint32_t tile, uint32_t tiles, uint32_t fine_bits,
                                                             uint32_t coarse_bins, const uint32_t* __restrict__ d_cnt /* [tile][bin] */,
@@ -291,31 +297,31 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_spread(const uint32_t* __re
                                                             uint32_t* __restrict__ d_prefix, uint32_t* __restrict__ d_total,
                                                             uint64_t* __restrict__ d_pairs) {
     __shared__ u32 s_cur[kMaxCoarse];
-    __shared__ u32 s_scan[kSortBlock];
+    __shared__ u32 s_scan[kRecodeBlock];
     const uint32_t t = threadIdx.x;
     // cursors of this tile: start of the bin (exclusive scan of the bin totals, <= 2048 values, in LDS) + the offset
-    // the tile took inside the bin (k_sort_count).  Thread t handles the bins t + 256 s.
-    constexpr uint32_t kStripes = kMaxCoarse / kSortBlock;
+    // the tile took inside the bin (k_sort_count).  Thread t handles the bins t + 1024 s.
+    constexpr uint32_t kStripes = kMaxCoarse / kRecodeBlock;
     u32 below[kStripes], all[kStripes];
 #pragma unroll
     for (uint32_t s = 0; s < kStripes; s++) {
-        const uint32_t q = t + s * kSortBlock;
+        const uint32_t q = t + s * kRecodeBlock;
         all[s] = q < coarse_bins ? d_binfill[q] : 0u;
         below[s] = q < coarse_bins ? d_cnt[(size_t)blockIdx.x * coarse_bins + q] : 0u;
     }
     u32 carry = 0, chunk_carry = 0;
 #pragma unroll
     for (uint32_t s = 0; s < kStripes; s++) {
-        if (s * kSortBlock >= coarse_bins) break;  // (uniform)
-        const uint32_t q = t + s * kSortBlock;
+        if (s * kRecodeBlock >= coarse_bins) break;  // (uniform)
+        const uint32_t q = t + s * kRecodeBlock;
         u32 stripe_total;
-        const u32 start = carry + block_exclusive_scan_256(all[s], s_scan, stripe_total);
+        const u32 start = carry + block_exclusive_scan_n<kRecodeBlock>(all[s], s_scan, stripe_total);
         __syncthreads();
         if (q < coarse_bins) s_cur[q] = start + below[s];
         if (blockIdx.x == 0) {  // what the fine passes need: bin starts and their chunk plan
             const u32 nch = q < coarse_bins ? (all[s] + ch - 1) / ch : 0u;
             u32 chunk_total;
-            const u32 cstart = chunk_carry + block_exclusive_scan_256(nch, s_scan, chunk_total);
+            const u32 cstart = chunk_carry + block_exclusive_scan_n<kRecodeBlock>(nch, s_scan, chunk_total);
             __syncthreads();
             if (q < coarse_bins) {
                 d_binstart[q] = start;
@@ -334,7 +340,7 @@ __global__ void __launch_bounds__(kSortBlock) k_sort_spread(const uint32_t* __re
     const uint64_t base = (uint64_t)blockIdx.x * tile;
     const uint64_t total = (uint64_t)bg.n * bg.batch;
     const u32 fine_mask = (1u << fine_bits) - 1u;
-    for (uint32_t off = threadIdx.x; off < tile; off += kSortBlock) {
+    for (uint32_t off = threadIdx.x; off < tile; off += kRecodeBlock) {
         uint64_t g = base + off;
         if (g >= total) break;
         uint32_t p = (uint32_t)(g / bg.n);
@@ -561,20 +567,22 @@ __global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const uint64_t* __r
 }
 
 // ---- exclusive scan of 256 values, one per thread -------------------------------------------------------------------
-__device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* lds, u32& total) {
-    // Hillis-Steele over 256 values in LDS
+template <int N>
+__device__ __forceinline__ u32 block_exclusive_scan_n(u32 v, u32* lds, u32& total) {
+    // Hillis-Steele over N values in LDS
     int t = threadIdx.x;
     lds[t] = v;
     __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
+    for (int off = 1; off < N; off <<= 1) {
         u32 add = t >= off ? lds[t - off] : 0u;
         __syncthreads();
         lds[t] += add;
         __syncthreads();
     }
-    total = lds[255];
+    total = lds[N - 1];
     return lds[t] - v;
 }
+__device__ __forceinline__ u32 block_exclusive_scan_256(u32 v, u32* lds, u32& total) { return block_exclusive_scan_n<256>(v, lds, total); }
 
 // ---- small inputs: the whole sort in one workgroup ----------------------------------------------------------
 // A commitment of a few thousand terms is bound by the latency of its chain of dependent kernels (the twelve
@@ -667,9 +675,9 @@ bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, u
     const uint32_t ch = fine_chunk_len(max_pairs);
     const uint32_t max_chunks = (uint32_t)((max_pairs + ch - 1) / ch) + g.coarse_bins;  // <= kFineMaxChunks
     uint32_t* d_binfill = d_ws + kWsBinFill;
-    hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, cfg, g.tile,
+    hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kRecodeBlock), 0, s, d_scalars, is_mont, bg, cfg, g.tile,
                        g.fine_bits, g.coarse_bins, d_cnt, d_binfill, d_header);
-    hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kSortBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg,
+    hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kRecodeBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg,
                        g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_binfill, ch, d_binstart, d_prefix, d_total, d_pairs);
     hipLaunchKernelGGL(k_fine_count, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_binstart, g.fine_bits,
                        g.coarse_bins, ch, d_prefix, d_table, d_binfill);
