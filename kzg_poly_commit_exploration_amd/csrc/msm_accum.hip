@@ -9,9 +9,11 @@
 // coefficients equal.  A lane closes a bucket it covers completely by storing it; the (at most two)
 // buckets it shares with its neighbours leave a head / tail partial that k_bucket_finalize adds up.
 //
-// Roofline: VALU issue bound (a wave-level v_mad_u64_u32 costs ~5.1 issue cycles, a simple instruction ~3.0).  Per reference 2770 v_mad_u64_u32 + ~3800 other VALU ops
-// against 96 B gathered from the table + 4 B of reference.  Algorithmic HBM bytes per commitment are
-// those of SURVEY.md section 8(d): 128 B x n + 144 B.
+// Roofline: VALU issue bound.  Per mixed addition the wave executes 3055 v_mad_i64_i32 (6 products x 2 x 13^2, two squares
+// x (91 + 13^2), and R (Q - X3) - Y1 PPP as two digit products under one reduction) + ~1400 other VALU instructions,
+// against one 128-byte table record gathered by LDS-DMA + 4 B of reference; it runs at the issue limit of that mix for
+// the two waves per SIMD its 243 VGPRs allow (profiles/r03_accum_isa_histogram.txt).
+// Algorithmic HBM bytes per commitment are those of SURVEY.md section 8(d): 128 B x n + 144 B.
 #include <cstdlib>
 
 #include "engine.h"
