@@ -201,6 +201,7 @@ int multi_create(const int* devices, int ndev, uint32_t mode, MultiState** out, 
         if (rc != KZG_OK) {
             for (auto* k : m->kids) kzg_ctx_destroy(k);
             delete m;
+            if (have_prev) (void)hipSetDevice(prev);
             return rc;
         }
         if (mode == kMultiRange) ctx_set_raw_partials(kid, true);
