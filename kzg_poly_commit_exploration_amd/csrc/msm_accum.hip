@@ -11,11 +11,18 @@
 //
 // Roofline: VALU issue bound.  Per mixed addition the wave executes 3055 v_mad_i64_i32 (6 products x 2 x 13^2, two squares
 // x (91 + 13^2), and R (Q - X3) - Y1 PPP as two digit products under one reduction) + ~1400 other VALU instructions,
-// against one 128-byte table record gathered by LDS-DMA + 4 B of reference; it runs at the issue limit of that mix for
-// the two waves per SIMD its 243 VGPRs allow (profiles/r03_accum_isa_histogram.txt).
+// against one 128-byte table record gathered by LDS-DMA + 4 B of reference; it runs within ~10 % of the sum of the two pipe
+// times of that mix (measured bare-loop rates), at two waves per SIMD as well as at three -- a three-wave form of the kernel
+// (no exceptional branches, 163 VGPRs, no spills) measured 2354 us against 2336 us (DESIGN.md section 4.4,
+// profiles/r03_accum_isa_histogram.txt).
 // Algorithmic HBM bytes per commitment are those of SURVEY.md section 8(d): 128 B x n + 144 B.
 #include <cstdlib>
 
+// the products of this translation unit keep their columns in program order (one live accumulator, field30.hip.h): the same
+// speed as the interleaved order at two waves per SIMD, and ~10 registers fewer for the kernels that run beside this one
+#ifndef KZG_ACCUM_PARALLEL_COLUMNS
+#define KZG_F30_SERIAL_COLUMNS 1
+#endif
 #include "engine.h"
 #include "field30_inv.hip.h"
 #include "g1_30.hip.h"
@@ -61,21 +68,58 @@ __device__ __forceinline__ uint32_t bucket_of(const uint32_t* __restrict__ offs,
 //   complete runs   -> buckets[b]
 //   run touching the segment start (bucket continues from the previous lane, or the whole segment
 //   lies inside one bucket) -> part_a[lane];  run touching only the segment end -> part_b[lane]
-#ifdef KZG_ACCUM_VGPRS  // experiments: cap the allocation below the 256 that two waves per SIMD allow
-#define KZG_ACCUM_ATTR __attribute__((amdgpu_num_vgpr(KZG_ACCUM_VGPRS)))
-#else
-#define KZG_ACCUM_ATTR
-#endif
+// The prefetch slot of a wave: [piece 0..7][lane] uint4, 8 KiB of the launch's dynamic LDS.  Its LDS byte address is kept as a
+// SCALAR (readfirstlane of a wave-uniform value the compiler cannot prove uniform): the LDS-DMA destination travels in M0, and
+// from a vector register the compiler carries eight of them, one per piece, each read back into M0 -- and, once they are
+// spilled, reloaded from scratch between the pieces behind a wait that serialises the gather.
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
+typedef uint32_t accum_u32x4 __attribute__((ext_vector_type(4)));  // (uint4 has no address-space-qualified copy constructor)
+typedef const __attribute__((address_space(3))) accum_u32x4* lds_u4_ptr;
+extern __shared__ uint4 lds_points[];
+// the lane's index in its wave from the execution hardware (two instructions, no register kept for it)
+__device__ __forceinline__ uint32_t accum_wave_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t accum_wave_slot() {
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_char_ptr)(char*)lds_points;
+    return lds0 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (8u * 64u * 16u);
+}
+// next point by LDS-DMA: eight 16-byte pieces per lane, destination = slot + piece * 1 KiB + lane * 16, no VGPR destination
+__device__ __forceinline__ void accum_issue_gather(const uint4* __restrict__ table, uint32_t slot, uint32_t r) {
+    const char* src = reinterpret_cast<const char*>(table + (size_t)(r & 0x7fffffffu) * kAffineU4);
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * k),
+                                         (__attribute__((address_space(3))) void*)(lds_char_ptr)(uintptr_t)(slot + 1024u * k),
+                                         16, 0, 0);
+}
+__device__ __forceinline__ Affine30 accum_take_point(uint32_t slot) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces (and the reference load behind them)
+    Affine30 r;
+    lds_u4_ptr q = (lds_u4_ptr)(uintptr_t)(slot + accum_wave_lane() * 16u);
+    const accum_u32x4 x0 = q[0], x1 = q[64], x2 = q[128], x3 = q[192];
+    const accum_u32x4 y0 = q[256], y1 = q[320], y2 = q[384], y3 = q[448];
+    r.x.d[0] = (int32_t)x0.x; r.x.d[1] = (int32_t)x0.y; r.x.d[2] = (int32_t)x0.z; r.x.d[3] = (int32_t)x0.w;
+    r.x.d[4] = (int32_t)x1.x; r.x.d[5] = (int32_t)x1.y; r.x.d[6] = (int32_t)x1.z; r.x.d[7] = (int32_t)x1.w;
+    r.x.d[8] = (int32_t)x2.x; r.x.d[9] = (int32_t)x2.y; r.x.d[10] = (int32_t)x2.z; r.x.d[11] = (int32_t)x2.w;
+    r.x.d[12] = (int32_t)x3.x;
+    r.y.d[0] = (int32_t)y0.x; r.y.d[1] = (int32_t)y0.y; r.y.d[2] = (int32_t)y0.z; r.y.d[3] = (int32_t)y0.w;
+    r.y.d[4] = (int32_t)y1.x; r.y.d[5] = (int32_t)y1.y; r.y.d[6] = (int32_t)y1.z; r.y.d[7] = (int32_t)y1.w;
+    r.y.d[8] = (int32_t)y2.x; r.y.d[9] = (int32_t)y2.y; r.y.d[10] = (int32_t)y2.z; r.y.d[11] = (int32_t)y2.w;
+    r.y.d[12] = (int32_t)y3.x;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot may be overwritten from here on
+    return r;
+}
+// sorted[i] with a 32-bit byte offset on the scalar base (the references of one job are < 2^30)
+__device__ __forceinline__ uint32_t accum_ref(const uint32_t* __restrict__ sorted, uint32_t i) {
+    return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(sorted) + (uint32_t)(i * 4u));
+}
+
 #ifndef KZG_ACCUM_MIN_BLOCKS
 #define KZG_ACCUM_MIN_BLOCKS 2
 #endif
-__global__ void KZG_ACCUM_ATTR __launch_bounds__(kAccumBlock, KZG_ACCUM_MIN_BLOCKS) k_bucket_accumulate(const uint4* __restrict__ table,
-                                                                  const uint32_t* __restrict__ sorted,
-                                                                  const uint32_t* __restrict__ offs, uint32_t nb,
-                                                                  uint32_t lanes, uint4* __restrict__ buckets,
-                                                                  uint4* __restrict__ part_a,
-                                                                  uint4* __restrict__ part_b,
-                                                                  unsigned long long* __restrict__ clk) {
+__global__ void __launch_bounds__(kAccumBlock, KZG_ACCUM_MIN_BLOCKS)
+k_bucket_accumulate(const uint4* __restrict__ table, const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offs,
+                    uint32_t nb, uint32_t lanes, uint4* __restrict__ buckets, uint4* __restrict__ part_a,
+                    uint4* __restrict__ part_b, unsigned long long* __restrict__ clk) {
     // clk (may be null): two zeroed words that receive max(~start) and max(end) over the waves of the launch, in ticks
     // of the constant 100 MHz clock -- the kernel's own duration, measured without a stream event on either side of it
     // (events between consecutive accumulation kernels cost the pipeline 8-10 %)
@@ -99,35 +143,10 @@ __global__ void KZG_ACCUM_ATTR __launch_bounds__(kAccumBlock, KZG_ACCUM_MIN_BLOC
     // (global_load_lds_dwordx4: per-lane source address, destination = wave base + lane * 16, no VGPR destination), so
     // the 26 registers of a point are live only across those two products instead of the whole addition.  The DMA has
     // the remaining 6M + 2S (~3500 instructions) to land; the table reference itself is read one step further ahead.
-    extern __shared__ uint4 lds_points[];  // [wave][piece 0..7][lane]: 8 KiB per wave (dynamic LDS of the launch)
-    uint4* const wave_slot = lds_points + (threadIdx.x >> 6) * (8 * 64);
-    const uint32_t wl = threadIdx.x & 63;
-    auto issue_gather = [&](uint32_t r) {
-        const char* src = reinterpret_cast<const char*>(table + (size_t)(r & 0x7fffffffu) * kAffineU4);
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 16 * k),
-                                             (__attribute__((address_space(3))) void*)(wave_slot + 64 * k), 16, 0, 0);
-    };
-    auto take_point = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces (and the reference load behind them)
-        Affine30 r;
-        const uint4 x0 = wave_slot[wl], x1 = wave_slot[64 + wl], x2 = wave_slot[128 + wl], x3 = wave_slot[192 + wl];
-        const uint4 y0 = wave_slot[256 + wl], y1 = wave_slot[320 + wl], y2 = wave_slot[384 + wl], y3 = wave_slot[448 + wl];
-        r.x.d[0] = (int32_t)x0.x; r.x.d[1] = (int32_t)x0.y; r.x.d[2] = (int32_t)x0.z; r.x.d[3] = (int32_t)x0.w;
-        r.x.d[4] = (int32_t)x1.x; r.x.d[5] = (int32_t)x1.y; r.x.d[6] = (int32_t)x1.z; r.x.d[7] = (int32_t)x1.w;
-        r.x.d[8] = (int32_t)x2.x; r.x.d[9] = (int32_t)x2.y; r.x.d[10] = (int32_t)x2.z; r.x.d[11] = (int32_t)x2.w;
-        r.x.d[12] = (int32_t)x3.x;
-        r.y.d[0] = (int32_t)y0.x; r.y.d[1] = (int32_t)y0.y; r.y.d[2] = (int32_t)y0.z; r.y.d[3] = (int32_t)y0.w;
-        r.y.d[4] = (int32_t)y1.x; r.y.d[5] = (int32_t)y1.y; r.y.d[6] = (int32_t)y1.z; r.y.d[7] = (int32_t)y1.w;
-        r.y.d[8] = (int32_t)y2.x; r.y.d[9] = (int32_t)y2.y; r.y.d[10] = (int32_t)y2.z; r.y.d[11] = (int32_t)y2.w;
-        r.y.d[12] = (int32_t)y3.x;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot may be overwritten from here on
-        return r;
-    };
-    uint32_t ref = sorted[start];
-    uint32_t ref_next = start + 1 < end ? sorted[start + 1] : 0u;
-    issue_gather(ref);
+    const uint32_t wave_slot = accum_wave_slot();  // [piece 0..7][lane]: 8 KiB per wave (dynamic LDS of the launch)
+    uint32_t ref = accum_ref(sorted, start);
+    uint32_t ref_next = accum_ref(sorted, min(start + 1, M - 1));
+    accum_issue_gather(table, wave_slot, ref);
     for (uint32_t e = start; e < end; e++) {
         if (e == b_end) {
             // bucket b ends here: flush its run and move to the bucket that owns e (skipping empties)
@@ -150,14 +169,15 @@ __global__ void KZG_ACCUM_ATTR __launch_bounds__(kAccumBlock, KZG_ACCUM_MIN_BLOC
         Fq P, R;
         bool more;
         {
-            const Affine30 p = take_point();
+            const Affine30 p = accum_take_point(wave_slot);
             more = xyzz30_madd_head(acc, p, (ref >> 31) != 0, P, R);
         }
-        if (e + 1 < end) {
-            ref = ref_next;
-            issue_gather(ref);
-            if (e + 2 < end) ref_next = sorted[e + 2];
-        }
+        // The next reference and the load of the one after it are UNCONDITIONAL (the index clamped to the job's last
+        // reference; past the segment's end the values are not used): assigned under a condition, the loaded word is
+        // merged with the old one by a move right here -- behind a wait that exposes the gather's whole latency.
+        ref = ref_next;
+        if (e + 1 < end) accum_issue_gather(table, wave_slot, ref);
+        ref_next = accum_ref(sorted, min(e + 2, M - 1));  // waited for at the next point, an addition from here
         if (more) xyzz30_madd_tail(acc, P, R);
     }
     // last run: [run_start, end)
@@ -227,7 +247,6 @@ __global__ void __launch_bounds__(kAccumBlock, 2) k_bucket_accumulate_pairs(cons
     // record (j, piece) of this lane: ((j * 4 + piece) * lanes + lane): a wave touches 1 KiB contiguous per piece
     auto rec = [&](uint32_t j, uint32_t piece) { return prefix_buf + ((size_t)(j * kPairRecU4 + piece) * lanes + lane); };
     // LDS: two point slots per wave (first and second reference of a pair slot), 8 pieces x 64 lanes x 16 B each
-    extern __shared__ uint4 lds_points[];
     uint4* const slot0 = lds_points + (threadIdx.x >> 6) * (16 * 64);
     uint4* const slot1 = slot0 + 8 * 64;
     const uint32_t wl = threadIdx.x & 63;
