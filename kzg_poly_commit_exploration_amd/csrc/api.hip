@@ -44,7 +44,10 @@ constexpr size_t kMaxCoefficients = 0xFFFFFFFFull;
 // kernel takes 260, the trees 1 ms).  With three jobs in flight the next job's sort regularly finished 100-240 us after
 // the accumulation it should have hidden under; five give it one more accumulation's worth of time: 366 -> 389
 // commitments/s on the same box (4: 383-390, 6: 381-385, 7: 368-385).
-constexpr int kNumSlots = 5;
+#ifndef KZG_NUM_SLOTS
+#define KZG_NUM_SLOTS 5
+#endif
+constexpr int kNumSlots = KZG_NUM_SLOTS;
 // Reduction plan (msm_reduce.hip): bucket index b = hi * C + lo; Row (R entries) and Col (C entries)
 // are each split once more into a "row" part and a "column" part that the host receives.
 struct ReducePlan {
