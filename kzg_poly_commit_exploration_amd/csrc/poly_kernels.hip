@@ -27,11 +27,16 @@
 // Every power of z a lane needs (z^8 and its repeated squares for the scan inside a workgroup, z^2048 and the
 // powers of the block stage, the 2 x 16 entry table of the replay) is computed ONCE on the host (~60 Fr products,
 // host_fr.hpp) and travels as a kernel argument.
+// Arithmetic: fr30.hip.h -- signed radix-2^30 digits, 162 multiply-adds per product instead of the ~500 instructions of
+// the 8 x u32 carry chain.  The coefficients and every value that leaves the scan keep the ABI's form (x * 2^256, canonical
+// 8 x u32); every multiplier is a power of z the host prepares as digits of w * 2^270 (fr30_host.hpp), so a product of a
+// value and a multiplier is a value again and nothing is ever converted by multiplying.  Values inside the scan are lazy
+// (a few r in magnitude, digits carry-normalised before each product); chunk values and aggregates travel between the two
+// launches as digits (12 words), a result is made canonical where it leaves (fr30_to_limbs).
 // Algorithmic bytes: 32 B read + 32 B written per coefficient; the coefficients are read
-// twice (96 B per coefficient at the memory controller).  HBM / latency bound.
+// twice (96 B per coefficient at the memory controller).  Bound by the Fr products at the occupancy 2^20 coefficients give.
 #include "engine.h"
-#include "field.hip.h"
-#include "host_fr.hpp"
+#include "fr30_host.hpp"
 
 #include <cstring>
 
@@ -43,34 +48,77 @@ constexpr int kPolyL = 8;        // coefficients per lane.  Alone at 2^20: 4 -> 
 constexpr int kPolyBlock = 256;  // lanes per workgroup
 constexpr int kPolyTile = kPolyL * kPolyBlock;
 
-size_t poly_chunk_words(uint32_t n) { return ((size_t)(n + kPolyTile - 1) / kPolyTile) * kPolyBlock * 8; }
-size_t poly_block_words(uint32_t n) { return ((size_t)(n + kPolyTile - 1) / kPolyTile + 1) * 8; }
+constexpr int kPolyRec = 12;     // words of a value in digit form between the launches (9 digits, padded to 3 x 16 bytes)
+size_t poly_chunk_words(uint32_t n) { return ((size_t)(n + kPolyTile - 1) / kPolyTile) * kPolyBlock * kPolyRec; }
+size_t poly_block_words(uint32_t n) { return ((size_t)(n + kPolyTile - 1) / kPolyTile + 1) * kPolyRec; }
 
-KZG_DEV Fr load_fr(const uint32_t* __restrict__ p) {
-    const uint4* q = reinterpret_cast<const uint4*>(p);
-    uint4 lo = q[0], hi = q[1];
-    Fr a;
-    a.l[0] = lo.x; a.l[1] = lo.y; a.l[2] = lo.z; a.l[3] = lo.w;
-    a.l[4] = hi.x; a.l[5] = hi.y; a.l[6] = hi.z; a.l[7] = hi.w;
-    return a;
-}
-KZG_DEV void store_fr(uint32_t* __restrict__ p, const Fr& a) {
-    uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(a.l[0], a.l[1], a.l[2], a.l[3]);
-    q[1] = make_uint4(a.l[4], a.l[5], a.l[6], a.l[7]);
-}
+#define KZG_DEV __device__ __forceinline__
+
+// a multiplier prepared by the host: digits of w * 2^270 (fr30_host.hpp)
 struct FrArg {
-    uint32_t l[8];
+    int32_t d[kR9];
 };
-KZG_DEV Fr fr_from_arg(const FrArg& a) {
-    Fr r;
+KZG_DEV Fr30 fr_from_arg(const FrArg& a) {
+    Fr30 r;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r.l[i] = a.l[i];
+    for (int i = 0; i < kR9; i++) r.d[i] = a.d[i];
     return r;
+}
+// value = value * multiplier + value (Horner step), carry-normalised
+KZG_DEV Fr30 fr30_mul_add(const Fr30& h, const Fr30& mult, const Fr30& c) { return fr30_norm(fr30_add_raw(fr30_mul(h, mult), c)); }
+// coefficient in the ABI's form -> digits
+KZG_DEV Fr30 fr30_from_u4(const uint4& lo, const uint4& hi) {
+    const uint32_t l[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return fr30_from_limbs(l);
+}
+KZG_DEV Fr30 load_coeff(const uint32_t* __restrict__ p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    return fr30_from_u4(q[0], q[1]);
+}
+// canonical 8 x u32 of a lazy value in (-r, 2r)
+KZG_DEV void store_canonical(uint32_t* __restrict__ p, const Fr30& a) {
+    uint32_t l[8];
+    fr30_to_limbs(a, l);
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(l[0], l[1], l[2], l[3]);
+    q[1] = make_uint4(l[4], l[5], l[6], l[7]);
+}
+// digit records between the launches: one 12-word record per value (aggregates), or three planes of uint4 (chunk values:
+// plane p of lane t at [p * lanes + t], consecutive lanes on consecutive words)
+KZG_DEV Fr30 load_rec(const uint32_t* __restrict__ p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    const uint4 a = q[0], b = q[1], c = q[2];
+    Fr30 r;
+    r.d[0] = (int32_t)a.x; r.d[1] = (int32_t)a.y; r.d[2] = (int32_t)a.z; r.d[3] = (int32_t)a.w;
+    r.d[4] = (int32_t)b.x; r.d[5] = (int32_t)b.y; r.d[6] = (int32_t)b.z; r.d[7] = (int32_t)b.w;
+    r.d[8] = (int32_t)c.x;
+    return r;
+}
+KZG_DEV void store_rec(uint32_t* __restrict__ p, const Fr30& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4((uint32_t)a.d[0], (uint32_t)a.d[1], (uint32_t)a.d[2], (uint32_t)a.d[3]);
+    q[1] = make_uint4((uint32_t)a.d[4], (uint32_t)a.d[5], (uint32_t)a.d[6], (uint32_t)a.d[7]);
+    q[2] = make_uint4((uint32_t)a.d[8], 0u, 0u, 0u);
+}
+KZG_DEV Fr30 load_planes(const uint32_t* __restrict__ base, size_t lanes, size_t t) {
+    const uint4* q = reinterpret_cast<const uint4*>(base);
+    const uint4 a = q[t], b = q[lanes + t], c = q[2 * lanes + t];
+    Fr30 r;
+    r.d[0] = (int32_t)a.x; r.d[1] = (int32_t)a.y; r.d[2] = (int32_t)a.z; r.d[3] = (int32_t)a.w;
+    r.d[4] = (int32_t)b.x; r.d[5] = (int32_t)b.y; r.d[6] = (int32_t)b.z; r.d[7] = (int32_t)b.w;
+    r.d[8] = (int32_t)c.x;
+    return r;
+}
+KZG_DEV void store_planes(uint32_t* __restrict__ base, size_t lanes, size_t t, const Fr30& a) {
+    uint4* q = reinterpret_cast<uint4*>(base);
+    q[t] = make_uint4((uint32_t)a.d[0], (uint32_t)a.d[1], (uint32_t)a.d[2], (uint32_t)a.d[3]);
+    q[lanes + t] = make_uint4((uint32_t)a.d[4], (uint32_t)a.d[5], (uint32_t)a.d[6], (uint32_t)a.d[7]);
+    q[2 * lanes + t] = make_uint4((uint32_t)a.d[8], 0u, 0u, 0u);
 }
 // powers of z prepared on the host (launch_quotient)
 struct PolyPowers {
     FrArg z;
+    FrArg one;         // 1: a product by it brings a lazy value back under r / 2 in magnitude
     FrArg zl_sq[8];    // (z^L)^(2^s): multipliers of the scan inside a workgroup
     FrArg zb;          // z^(L * 256): one workgroup up
     FrArg zbp_sq[8];   // (zb^per)^(2^s): multipliers of the scan over the lanes of the block stage (more than kPolyDirectBlocks blocks)
@@ -80,21 +128,22 @@ struct PolyPowers {
     FrArg pa[16];      // (z^L)^(16 e)
     FrArg pb[16];      // (z^L)^e
 };
+constexpr int kPolyScanWords = kPolyBlock * kR9;  // LDS words of the exchanges below
 // Kogge-Stone suffix scan over the workgroup: v_t <- sum_{u >= t} v_u * mult^(u - t)
 template <int BLOCK>
-KZG_DEV Fr block_suffix_scan(Fr v, const FrArg* mults /* mult^(2^s), s < log2(BLOCK) */, uint32_t* lds /* BLOCK * 8 words */) {
+KZG_DEV Fr30 block_suffix_scan(Fr30 v, const FrArg* mults /* mult^(2^s), s < log2(BLOCK) */, uint32_t* lds /* BLOCK * 9 words */) {
     const int t = threadIdx.x;
     int s = 0;
     for (int off = 1; off < BLOCK; off <<= 1, s++) {
-        const Fr mult = fr_from_arg(mults[s]);
+        const Fr30 mult = fr_from_arg(mults[s]);
 #pragma unroll
-        for (int i = 0; i < 8; i++) lds[i * BLOCK + t] = v.l[i];
+        for (int i = 0; i < kR9; i++) lds[i * BLOCK + t] = (uint32_t)v.d[i];
         __syncthreads();
         if (t + off < BLOCK) {
-            Fr o;
+            Fr30 o;
 #pragma unroll
-            for (int i = 0; i < 8; i++) o.l[i] = lds[i * BLOCK + t + off];
-            v = fe_add(v, fe_mul(mult, o));
+            for (int i = 0; i < kR9; i++) o.d[i] = (int32_t)lds[i * BLOCK + t + off];
+            v = fr30_mul_add(o, mult, v);
         }
         __syncthreads();
     }
@@ -135,12 +184,10 @@ KZG_DEV void poly_stage_in(const uint32_t* __restrict__ coeffs, uint64_t first, 
     }
     poly_wave_sync();
 }
-KZG_DEV Fr poly_lds_coeff(const uint4* __restrict__ lds_wave, uint32_t lane, int k) {
+KZG_DEV Fr30 poly_lds_coeff(const uint4* __restrict__ lds_wave, uint32_t lane, int k, bool* nonzero = nullptr) {
     const uint4 lo = lds_wave[17u * lane + 2u * (uint32_t)k], hi = lds_wave[17u * lane + 2u * (uint32_t)k + 1u];
-    Fr a;
-    a.l[0] = lo.x; a.l[1] = lo.y; a.l[2] = lo.z; a.l[3] = lo.w;
-    a.l[4] = hi.x; a.l[5] = hi.y; a.l[6] = hi.z; a.l[7] = hi.w;
-    return a;
+    if (nonzero) *nonzero = ((lo.x | lo.y | lo.z | lo.w) | (hi.x | hi.y | hi.z | hi.w)) != 0u;
+    return fr30_from_u4(lo, hi);
 }
 
 // single workgroup's worth of work: carries for every block.  d_block[b] in: aggregate of block b (zero carry-in);
@@ -148,30 +195,30 @@ KZG_DEV Fr poly_lds_coeff(const uint4* __restrict__ lds_wave, uint32_t lane, int
 // Lane t owns `per` consecutive blocks: Horner over its blocks, Kogge-Stone across lanes, replay.
 KZG_DEV void poly_block_stage(uint32_t* __restrict__ d_block, uint32_t nblocks, const PolyPowers& pw, uint32_t* __restrict__ d_result,
                               uint32_t* lds) {
-    const Fr zb = fr_from_arg(pw.zb);  // one block up
+    const Fr30 zb = fr_from_arg(pw.zb);  // one block up
     const uint32_t t = threadIdx.x;
     const uint32_t per = (nblocks + kPolyBlock - 1) / kPolyBlock;
     const uint32_t lo = t * per < nblocks ? t * per : nblocks;
     const uint32_t hi = lo + per < nblocks ? lo + per : nblocks;
-    Fr h = Fr::zero();
-    for (uint32_t u = hi; u-- > lo;) h = fe_add(fe_mul(h, zb), load_fr(d_block + (size_t)u * 8));
+    Fr30 h = fr30_zero();
+    for (uint32_t u = hi; u-- > lo;) h = fr30_mul_add(h, zb, load_rec(d_block + (size_t)u * kPolyRec));
     // H_t = sum_{v >= t} h_v * (zb^per)^(v - t)
-    Fr H = block_suffix_scan<kPolyBlock>(h, pw.zbp_sq, lds);
+    Fr30 H = block_suffix_scan<kPolyBlock>(h, pw.zbp_sq, lds);
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; i++) lds[i * kPolyBlock + t] = H.l[i];
+    for (int i = 0; i < kR9; i++) lds[i * kPolyBlock + t] = (uint32_t)H.d[i];
     __syncthreads();
-    Fr s = Fr::zero();  // S at the first coefficient of the next lane's first block
+    Fr30 s = fr30_zero();  // S at the first coefficient of the next lane's first block
     if (t + 1 < (uint32_t)kPolyBlock) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) s.l[i] = lds[i * kPolyBlock + t + 1];
+        for (int i = 0; i < kR9; i++) s.d[i] = (int32_t)lds[i * kPolyBlock + t + 1];
     }
     for (uint32_t u = hi; u-- > lo;) {
-        Fr a = load_fr(d_block + (size_t)u * 8);
-        store_fr(d_block + (size_t)u * 8, s);  // carry-in of block u = S at the start of block u+1
-        s = fe_add(fe_mul(s, zb), a);
+        const Fr30 a = load_rec(d_block + (size_t)u * kPolyRec);
+        store_rec(d_block + (size_t)u * kPolyRec, s);  // carry-in of block u = S at the start of block u+1
+        s = fr30_mul_add(s, zb, a);
     }
-    if (t == 0) store_fr(d_result, s);  // S[0] = P(z)
+    if (t == 0) store_canonical(d_result, fr30_mul(s, fr_from_arg(pw.one)));  // S[0] = P(z)
 }
 
 // d_flags: the job's flag words -- [0] |= any non-zero coefficient with index >= 1, [16..23] receive c[0] (what the
@@ -181,67 +228,71 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_chunks(const uint32_t* __re
                                                             uint32_t* __restrict__ d_block,
                                                             uint32_t* __restrict__ d_flags) {
     extern __shared__ uint4 lds_tile[];                       // 4 waves x kPolyWaveLds uint4
-    __shared__ uint32_t lds[kPolyBlock * 8];
-    const Fr z = fr_from_arg(pw.z);
+    __shared__ uint32_t lds[kPolyScanWords];
+    const Fr30 z = fr_from_arg(pw.z);
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint4* lds_wave = lds_tile + wave * kPolyWaveLds;
     const uint32_t t = blockIdx.x * kPolyBlock + threadIdx.x;
     const uint64_t wave_first = ((uint64_t)blockIdx.x * kPolyBlock + wave * 64u) * kPolyL;
     poly_stage_in(coeffs, wave_first, n, lds_wave, lane);
-    Fr h = Fr::zero();
+    Fr30 h = fr30_zero();
     bool nz = false;
 #pragma unroll
     for (int k = kPolyL - 1; k >= 0; k--) {
-        const Fr c = poly_lds_coeff(lds_wave, lane, k);
-        if (((uint64_t)t * kPolyL + k) >= 1 && !c.is_zero()) nz = true;  // (coefficients past n were staged as zero)
-        h = fe_add(fe_mul(h, z), c);
+        bool c_nz;
+        const Fr30 c = poly_lds_coeff(lds_wave, lane, k, &c_nz);
+        if (((uint64_t)t * kPolyL + k) >= 1 && c_nz) nz = true;  // (coefficients past n were staged as zero)
+        h = fr30_mul_add(h, z, c);
     }
     if (__any(nz) && lane == 0) d_flags[0] = 1u;  // (the flag words are host-mapped: plain stores, every writer stores 1)
-    if (t == 0) store_fr(d_flags + 16, poly_lds_coeff(lds_wave, 0, 0));  // c[0]
+    if (t == 0) {  // c[0], as it came
+        reinterpret_cast<uint4*>(d_flags + 16)[0] = lds_wave[0];
+        reinterpret_cast<uint4*>(d_flags + 16)[1] = lds_wave[1];
+    }
     h = block_suffix_scan<kPolyBlock>(h, pw.zl_sq, lds);
-    store_fr(d_chunk + (size_t)t * 8, h);
-    if (threadIdx.x == 0) store_fr(d_block + (size_t)blockIdx.x * 8, h);
+    store_planes(d_chunk, (size_t)gridDim.x * kPolyBlock, t, h);
+    if (threadIdx.x == 0) store_rec(d_block + (size_t)blockIdx.x * kPolyRec, h);
 }
 
 __global__ void __launch_bounds__(kPolyBlock) k_poly_blocks(uint32_t* __restrict__ d_block, uint32_t nblocks, PolyPowers pw,
                                                             uint32_t* __restrict__ d_result) {
-    __shared__ uint32_t lds[kPolyBlock * 8];
+    __shared__ uint32_t lds[kPolyScanWords];
     poly_block_stage(d_block, nblocks, pw, d_result, lds);
 }
 
 // C_b = sum_{u > b} A_u zb^(u-b-1) for this workgroup's block b (b = -1: everything, i.e. P(z)): terms spread over the
 // lanes, summed by an addition tree through LDS; every lane returns the sum
 constexpr uint32_t kPolyDirectBlocks = 1024;  // beyond: k_poly_blocks prepares the carries
-KZG_DEV Fr poly_carry_from_aggregates(const uint32_t* __restrict__ d_block, uint32_t nblocks, uint32_t first /* b + 1 */,
-                                      const PolyPowers& pw, uint32_t* lds /* kPolyBlock * 8 words */) {
+KZG_DEV Fr30 poly_carry_from_aggregates(const uint32_t* __restrict__ d_block, uint32_t nblocks, uint32_t first /* b + 1 */,
+                                        const PolyPowers& pw, uint32_t* lds /* kPolyBlock * 9 words */) {
     const uint32_t t = threadIdx.x;
-    Fr sum = Fr::zero();
+    Fr30 sum = fr30_zero();
     if (first + t < nblocks) {
-        Fr power = fe_mul(fr_from_arg(pw.ba[t >> 4]), fr_from_arg(pw.bb[t & 15]));  // zb^t
-        const Fr stride = fr_from_arg(pw.zb256);
+        Fr30 power = fr30_mul(fr_from_arg(pw.ba[t >> 4]), fr_from_arg(pw.bb[t & 15]));  // zb^t (a multiplier again)
+        const Fr30 stride = fr_from_arg(pw.zb256);
         for (uint32_t u = first + t; u < nblocks; u += kPolyBlock) {
-            sum = fe_add(sum, fe_mul(load_fr(d_block + (size_t)u * 8), power));
-            if (u + kPolyBlock < nblocks) power = fe_mul(power, stride);
+            sum = fr30_mul_add(load_rec(d_block + (size_t)u * kPolyRec), power, sum);
+            if (u + kPolyBlock < nblocks) power = fr30_mul(power, stride);
         }
     }
     for (int off = kPolyBlock / 2; off >= 1; off >>= 1) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) lds[i * kPolyBlock + t] = sum.l[i];
+        for (int i = 0; i < kR9; i++) lds[i * kPolyBlock + t] = (uint32_t)sum.d[i];
         __syncthreads();
         if ((int)t < off) {
-            Fr o;
+            Fr30 o;
 #pragma unroll
-            for (int i = 0; i < 8; i++) o.l[i] = lds[i * kPolyBlock + t + off];
-            sum = fe_add(sum, o);
+            for (int i = 0; i < kR9; i++) o.d[i] = (int32_t)lds[i * kPolyBlock + t + off];
+            sum = fr30_add(sum, o);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) lds[i * kPolyBlock + t] = sum.l[i];
+    for (int i = 0; i < kR9; i++) lds[i * kPolyBlock + t] = (uint32_t)sum.d[i];
     __syncthreads();
-    Fr total;
+    Fr30 total;
 #pragma unroll
-    for (int i = 0; i < 8; i++) total.l[i] = lds[i * kPolyBlock];
+    for (int i = 0; i < kR9; i++) total.d[i] = (int32_t)lds[i * kPolyBlock];
     return total;
 }
 
@@ -252,8 +303,8 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_apply(const uint32_t* __res
                                                            const uint32_t* __restrict__ d_block, uint32_t nblocks, int direct,
                                                            uint32_t* __restrict__ d_q, uint32_t* __restrict__ d_result) {
     extern __shared__ uint4 lds_tile[];
-    __shared__ uint32_t lds[kPolyBlock * 8];
-    const Fr z = fr_from_arg(pw.z);
+    __shared__ uint32_t lds[kPolyScanWords];
+    const Fr30 z = fr_from_arg(pw.z);
     const int tl = threadIdx.x;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint4* lds_wave = lds_tile + wave * kPolyWaveLds;
@@ -261,30 +312,35 @@ __global__ void __launch_bounds__(kPolyBlock) k_poly_apply(const uint32_t* __res
     const uint64_t wave_first = ((uint64_t)blockIdx.x * kPolyBlock + wave * 64u) * kPolyL;
     if (d_q) poly_stage_in(coeffs, wave_first, n, lds_wave, lane);  // in flight while the carry is worked out
     // carry into this workgroup's block = S at the first coefficient of the next block
-    Fr blk_carry;
+    Fr30 blk_carry;
     if (direct) {
         blk_carry = poly_carry_from_aggregates(d_block, nblocks, blockIdx.x + 1, pw, lds);
-        if (blockIdx.x == 0 && tl == 0)  // P(z) = S[0] = A_0 + zb C_0
-            store_fr(d_result, fe_add(load_fr(d_block), fe_mul(fr_from_arg(pw.zb), blk_carry)));
+        if (blockIdx.x == 0 && tl == 0) {  // P(z) = S[0] = A_0 + zb C_0, brought under r / 2 by a product with one
+            const Fr30 s0 = fr30_mul_add(blk_carry, fr_from_arg(pw.zb), load_rec(d_block));
+            store_canonical(d_result, fr30_mul(s0, fr_from_arg(pw.one)));
+        }
     } else {
-        blk_carry = load_fr(d_block + (size_t)blockIdx.x * 8);
+        blk_carry = load_rec(d_block + (size_t)blockIdx.x * kPolyRec);
     }
     if (!d_q) return;
-    Fr h;
+    Fr30 h;
     uint32_t dist = (uint32_t)(kPolyBlock - 1 - tl);  // chunks between the next chunk and the block end
-    const Fr pa = fr_from_arg(pw.pa[dist >> 4]), pb = fr_from_arg(pw.pb[dist & 15]);  // (z^L)^dist = pa * pb
-    Fr scaled = fe_mul(fe_mul(pa, pb), blk_carry);
+    const Fr30 pa = fr_from_arg(pw.pa[dist >> 4]), pb = fr_from_arg(pw.pb[dist & 15]);  // (z^L)^dist = pa * pb
+    const Fr30 scaled = fr30_mul(blk_carry, fr30_mul(pa, pb));
     if (tl + 1 < kPolyBlock) {
-        h = fe_add(load_fr(d_chunk + (size_t)(t + 1) * 8), scaled);
+        h = fr30_add(load_planes(d_chunk, (size_t)gridDim.x * kPolyBlock, (size_t)t + 1), scaled);
     } else {
         h = scaled;  // dist == 0: the block carry itself
     }
-    // replay: S at every coefficient of the chunk, written back into the lane's own LDS words
+    // replay: S at every coefficient of the chunk (a product plus a canonical coefficient: inside (-r, 2r)), written back
+    // canonical into the lane's own LDS words
 #pragma unroll
     for (int k = kPolyL - 1; k >= 0; k--) {
-        h = fe_add(fe_mul(h, z), poly_lds_coeff(lds_wave, lane, k));
-        lds_wave[17u * lane + 2u * (uint32_t)k] = make_uint4(h.l[0], h.l[1], h.l[2], h.l[3]);
-        lds_wave[17u * lane + 2u * (uint32_t)k + 1u] = make_uint4(h.l[4], h.l[5], h.l[6], h.l[7]);
+        h = fr30_mul_add(h, z, poly_lds_coeff(lds_wave, lane, k));
+        uint32_t l[8];
+        fr30_to_limbs(h, l);
+        lds_wave[17u * lane + 2u * (uint32_t)k] = make_uint4(l[0], l[1], l[2], l[3]);
+        lds_wave[17u * lane + 2u * (uint32_t)k + 1u] = make_uint4(l[4], l[5], l[6], l[7]);
     }
     poly_wave_sync();
     // q[i - 1] = S[i]: the wave's 512 values go out one coefficient lower, consecutive lanes on consecutive words
@@ -305,48 +361,53 @@ constexpr uint32_t kPolySingleL = 16;
 constexpr uint32_t kPolySingleMax = kPolySingleL * kPolyBlock;  // 4096
 __global__ void __launch_bounds__(kPolyBlock) k_poly_single(const uint32_t* __restrict__ coeffs, uint32_t n, PolyPowers pw,
                                                             uint32_t* __restrict__ d_q, uint32_t* __restrict__ d_small) {
-    __shared__ uint32_t lds[kPolyBlock * 8];
-    const Fr z = fr_from_arg(pw.z);
+    __shared__ uint32_t lds[kPolyScanWords];
+    const Fr30 z = fr_from_arg(pw.z);
     const uint32_t t = threadIdx.x;
     const uint32_t base = t * kPolySingleL;
-    Fr h = Fr::zero();
+    Fr30 h = fr30_zero();
     bool nz = false;
 #pragma unroll 1
     for (int k = (int)kPolySingleL - 1; k >= 0; k--) {
         const uint32_t idx = base + k;
-        h = fe_mul(h, z);
+        Fr30 c = fr30_zero();
         if (idx < n) {
-            const Fr c = load_fr(coeffs + (size_t)idx * 8);
-            if (idx >= 1 && !c.is_zero()) nz = true;
-            h = fe_add(h, c);
+            const uint4* q = reinterpret_cast<const uint4*>(coeffs + (size_t)idx * 8);
+            const uint4 lo = q[0], hi = q[1];
+            if (idx >= 1 && ((lo.x | lo.y | lo.z | lo.w) | (hi.x | hi.y | hi.z | hi.w)) != 0u) nz = true;
+            c = fr30_from_u4(lo, hi);
         }
+        h = fr30_mul_add(h, z, c);
     }
     const int any_nz = __syncthreads_or(nz ? 1 : 0);
     h = block_suffix_scan<kPolyBlock>(h, pw.zl_sq, lds);  // S at the first coefficient of this lane's chunk
 #pragma unroll
-    for (int i = 0; i < 8; i++) lds[i * kPolyBlock + t] = h.l[i];
+    for (int i = 0; i < kR9; i++) lds[i * kPolyBlock + t] = (uint32_t)h.d[i];
     __syncthreads();
     if (t < 64) d_small[t] = 0;
     __syncthreads();
     if (t == 0) {
         d_small[0] = any_nz ? 1u : 0u;
-        store_fr(d_small + 8, h);  // S[0] = P(z)
-        store_fr(d_small + 16, load_fr(coeffs));
+        store_canonical(d_small + 8, fr30_mul(h, fr_from_arg(pw.one)));  // S[0] = P(z)
+        const uint4* q = reinterpret_cast<const uint4*>(coeffs);
+        reinterpret_cast<uint4*>(d_small + 16)[0] = q[0];
+        reinterpret_cast<uint4*>(d_small + 16)[1] = q[1];
     }
     if (!d_q || n <= 1) return;
-    Fr carry = Fr::zero();  // S at the first coefficient of the next chunk
+    Fr30 carry = fr30_zero();  // S at the first coefficient of the next chunk
     if (t + 1 < (uint32_t)kPolyBlock) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) carry.l[i] = lds[i * kPolyBlock + t + 1];
+        for (int i = 0; i < kR9; i++) carry.d[i] = (int32_t)lds[i * kPolyBlock + t + 1];
     }
     h = carry;
 #pragma unroll 1
     for (int k = (int)kPolySingleL - 1; k >= 0; k--) {
         const uint32_t idx = base + k;
-        h = fe_mul(h, z);
         if (idx < n) {
-            h = fe_add(h, load_fr(coeffs + (size_t)idx * 8));
-            if (idx >= 1) store_fr(d_q + (size_t)(idx - 1) * 8, h);
+            h = fr30_mul_add(h, z, load_coeff(coeffs + (size_t)idx * 8));  // a product plus a canonical coefficient
+            if (idx >= 1) store_canonical(d_q + (size_t)(idx - 1) * 8, h);
+        } else {
+            h = fr30_mul(h, z);  // (past the end: h is zero and stays zero)
         }
     }
 }
@@ -366,10 +427,14 @@ bool launch_quotient_single(hipStream_t s, const uint32_t* d_coeffs, uint32_t n,
     namespace hf = kzg_host;
     PolyPowers pw;
     std::memset(&pw, 0, sizeof pw);
-    auto put = [](FrArg& dst, const hf::Fr& v) { std::memcpy(dst.l, v.l, 32); };
+    auto put = [](FrArg& dst, const hf::Fr& v) {  // the multiplier's form: digits of v * 2^270
+        const Fr30 d = fr30_arg_from_mont256(v);
+        std::memcpy(dst.d, d.d, sizeof dst.d);
+    };
     hf::Fr z;
     std::memcpy(z.l, z_mont, 32);
     put(pw.z, z);
+    put(pw.one, hf::kFrOne);
     hf::Fr m = hf::fr_pow(z, kPolySingleL);
     for (int k = 0; k < 8; k++) {  // (z^L)^(2^k)
         put(pw.zl_sq[k], m);
@@ -386,10 +451,14 @@ void launch_quotient(hipStream_t s, const uint32_t* d_coeffs, uint32_t n, const 
     const uint32_t nblocks = (n + kPolyTile - 1) / kPolyTile;
     const uint32_t per = (nblocks + kPolyBlock - 1) / kPolyBlock;  // blocks per lane of the block stage
     PolyPowers pw;
-    auto put = [](FrArg& dst, const hf::Fr& v) { std::memcpy(dst.l, v.l, 32); };
+    auto put = [](FrArg& dst, const hf::Fr& v) {  // the multiplier's form: digits of v * 2^270
+        const Fr30 d = fr30_arg_from_mont256(v);
+        std::memcpy(dst.d, d.d, sizeof dst.d);
+    };
     hf::Fr z;
     std::memcpy(z.l, z_mont, 32);
     put(pw.z, z);
+    put(pw.one, hf::kFrOne);
     hf::Fr zl = hf::fr_pow(z, kPolyL), m = zl;
     for (int k = 0; k < 8; k++) {  // zl^(2^k); after the loop m = zl^256 = z^(L * 256)
         put(pw.zl_sq[k], m);
