@@ -423,7 +423,7 @@ int enqueue_msm(kzg_ctx* ctx, Slot& s, const uint32_t* d_scalars, int is_mont, s
                                finalize_group_size(nbt));
         // (Rounds 1-2 put a gate kernel here that deferred the reduction trees to the tail of the next slot's
         // accumulation: worth 20 % with round 1's 206-VGPR accumulation kernel, beside which the trees could become
-        // resident; the 243-VGPR kernel fills the register file, the trees cannot start beside it whatever the stream
+        // resident; the trees (243-258 VGPRs) cannot start beside round 3's accumulation kernel whatever the stream
         // order says, and with or without a gate -- LDS-sized or a device-side count of running workgroups -- round 3
         // measured 409 / 384 against 408 / 383 and 414 / 386 against 415 / 386 commitments / proofs per second.  Retired.)
         launch_tree_sums_two_stage(st, stage1, 2, stage2, 4, (uint32_t*)s.d_heavy_ws + 64, alone);
