@@ -1,7 +1,7 @@
 // fr30.hip.h -- BLS12-381 scalar field Fr in a SIGNED radix-2^30 representation (9 int32 digits), Montgomery
 // products with R'' = 2^270, built for gfx950's v_mad_i64_i32 like field30.hip.h does for the base field.
 //
-// Why: the 8 x u32 Montgomery multiplier of field.hip.h is a carry chain -- per product 120 v_mad_u64_u32, 125 v_addc,
+// Why: an 8 x u32 Montgomery multiplier (rounds 1-2; tools/legacy_field/field.hip.h) is a carry chain -- per product 120 v_mad_u64_u32, 125 v_addc,
 // ~140 moves and ~90 s_nop for the carry-out hazards, ~500 instructions -- and the quotient scan and the scalar recoding
 // are bound by it.  With balanced 30-bit digits a column of the product (<= 9 digit products of a*b and 9 of m*r) stays
 // inside a signed 64-bit accumulator:
@@ -17,7 +17,8 @@
 // operands (|a| |b| < 2^528), sums are digit-wise and carry-normalised (fr30_norm) before they feed a product.
 //
 // Replaces blst's Fr arithmetic behind Scalar::add / mul (reference src/scalar.rs:55-81) inside Polynomial::evaluate and
-// divide_by_root (src/polynomial.rs:112-195).
+// divide_by_root (src/polynomial.rs:112-195), behind Scalar::to_le_bytes in front of every scalar multiplication
+// (src/scalar.rs:83-93: msm_sort.hip's load_scalar) and behind the powers of the secret (src/trusted_setup.rs:50).
 #pragma once
 #include <stdint.h>
 
@@ -48,6 +49,17 @@ KZG_HD constexpr int32_t fr30_rd(int i) {
 KZG_HD constexpr uint32_t fr30_ru(int i) {
     constexpr uint32_t RU[9] = {0x1, 0x3ffffffc, 0x3fe5bfef, 0x2f6900bf, 0x21d80553, 0x27602026, 0x17d48333, 0x29d4ca67, 0x73ed};
     return RU[i];
+}
+
+// 2^270 mod r (the one of variable x variable products, where both operands carry the factor 2^270) and 2^540 mod r (takes a
+// plain integer into that form), balanced digits of the centred residues
+KZG_HD constexpr int32_t fr30_one270(int i) {
+    constexpr int32_t C[9] = {-0x8d54, 0x23550, -0x21a2ac0, 0x1c22013a, -0x15d0deee, -0x1d3fc534, -0x1dfe7aaf, 0x12b2a695, 0x10dc};
+    return C[i];
+}
+KZG_HD constexpr int32_t fr30_r2_540(int i) {
+    constexpr int32_t C[9] = {0xefe9ec3, 0x1022c0f, 0x12313d61, 0x83bec60, -0xcc084be, 0x4a39dc, -0x17165989, 0x1dd02cf9, -0xc8f};
+    return C[i];
 }
 
 KZG_HD int32_t fr30_sext30(uint32_t v) { return (int32_t)(v << 2) >> 2; }  // low 30 bits as a balanced digit
@@ -107,8 +119,9 @@ KZG_HD Fr30 fr30_mul(const Fr30& a, const Fr30& b) {
     return r;
 }
 
-// the 256-bit integer in 8 x u32 (any value below 2^256) as balanced digits: pure re-slicing and one carry pass
-KZG_HD Fr30 fr30_from_limbs(const uint32_t l[8]) {
+// the 256-bit integer in 8 x u32 (any value below 2^256) as UNSIGNED digits (< 2^30): pure re-slicing.  Good enough as
+// the operand of a product whose other operand is a constant of balanced digits (the columns stay below 2^63 / 2).
+KZG_HD Fr30 fr30_from_limbs_raw(const uint32_t l[8]) {
     Fr30 u;
     u.d[0] = (int32_t)(l[0] & kR9Mask);
     u.d[1] = (int32_t)(((l[0] >> 30) | (l[1] << 2)) & kR9Mask);
@@ -119,7 +132,43 @@ KZG_HD Fr30 fr30_from_limbs(const uint32_t l[8]) {
     u.d[6] = (int32_t)(((l[5] >> 20) | (l[6] << 12)) & kR9Mask);
     u.d[7] = (int32_t)(((l[6] >> 18) | (l[7] << 14)) & kR9Mask);
     u.d[8] = (int32_t)(l[7] >> 16);
-    return fr30_norm(u);
+    return u;
+}
+// ... as balanced digits: one carry pass on top
+KZG_HD Fr30 fr30_from_limbs(const uint32_t l[8]) { return fr30_norm(fr30_from_limbs_raw(l)); }
+
+// |v| as a 256-bit integer in 8 x u32 and the sign of v, for a lazy value of magnitude below 2^256 (the scalar recoding:
+// v is a product, |v| <= r / 2 + r / 2^31, and its sign moves onto the point).  Sequential carry to unsigned digits with a
+// signed top digit, two's complement when negative.
+KZG_HD bool fr30_abs_to_limbs(const Fr30& a, uint32_t l[8]) {
+    uint32_t u[kR9];
+    int32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < kR9 - 1; i++) {
+        const int32_t t = a.d[i] + c;
+        u[i] = (uint32_t)t & kR9Mask;
+        c = t >> kR9Bits;  // floor
+    }
+    const int32_t top = a.d[kR9 - 1] + c;  // signed: the sign of the whole value
+    const bool neg = top < 0;
+    const uint32_t flip = neg ? kR9Mask : 0u;
+    uint32_t carry = neg ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < kR9 - 1; i++) {
+        const uint32_t t = (u[i] ^ flip) + carry;
+        u[i] = t & kR9Mask;
+        carry = t >> kR9Bits;
+    }
+    const uint32_t t8 = (neg ? ~(uint32_t)top : (uint32_t)top) + carry;
+    l[0] = u[0] | (u[1] << 30);
+    l[1] = (u[1] >> 2) | (u[2] << 28);
+    l[2] = (u[2] >> 4) | (u[3] << 26);
+    l[3] = (u[3] >> 6) | (u[4] << 24);
+    l[4] = (u[4] >> 8) | (u[5] << 22);
+    l[5] = (u[5] >> 10) | (u[6] << 20);
+    l[6] = (u[6] >> 12) | (u[7] << 18);
+    l[7] = (u[7] >> 14) | (t8 << 16);
+    return neg;
 }
 
 // The canonical residue in [0, r) as 8 x u32, for a lazy value in (-r, 2r): what the scans hold where a result leaves
@@ -167,6 +216,25 @@ KZG_HD void fr30_to_limbs(const Fr30& a, uint32_t l[8]) {
     l[5] = (u[5] >> 10) | (u[6] << 20);
     l[6] = (u[6] >> 12) | (u[7] << 18);
     l[7] = (u[7] >> 14) | (t8 << 16);
+}
+
+// the digits {c, 0, ..., 0} of a small constant: fr30_mul(x * 2^256, fr30_small(1 << 14)) = x, fr30_mul(x * 2^270, fr30_small(1)) = x
+KZG_HD Fr30 fr30_small(int32_t c) {
+    Fr30 r = fr30_zero();
+    r.d[0] = c;
+    return r;
+}
+KZG_HD Fr30 fr30_const_one270() {
+    Fr30 r;
+#pragma unroll
+    for (int i = 0; i < kR9; i++) r.d[i] = fr30_one270(i);
+    return r;
+}
+KZG_HD Fr30 fr30_const_r2_540() {
+    Fr30 r;
+#pragma unroll
+    for (int i = 0; i < kR9; i++) r.d[i] = fr30_r2_540(i);
+    return r;
 }
 
 }  // namespace kzg

@@ -10,9 +10,14 @@
 #include <cstring>
 
 #include "engine.h"
-#include "field.hip.h"
+#include "fr30.hip.h"
 
 namespace kzg {
+
+typedef uint32_t u32;
+#ifndef KZG_DEV
+#define KZG_DEV __device__ __forceinline__
+#endif
 
 static uint32_t ilog2(uint32_t v) {
     uint32_t b = 0;
@@ -73,36 +78,22 @@ MsmConfig choose_msm_config(size_t n, size_t table_budget_bytes) {
     return cfg;
 }
 
-// canonical 256-bit scalar (8 words) from the stored form, folded to the shorter of k and r - k:
-// k * P = (r - k) * (-P).  Returns true when the point has to be negated.  Besides halving the
-// range this makes the reference's "negative" i128 inputs (r - |a|, src/scalar.rs:27-48) as cheap
-// as the positive ones: their upper windows become zero digits, which are skipped.
+// The scalar as sign and magnitude of its shortest representative: |k| <= r / 2 (+ r / 2^31) < 2^254 in 8 words, and
+// k * P = |k| * (+-P).  Returns true when the point has to be negated.  Besides halving the range this makes the
+// reference's "negative" i128 inputs (r - |a|, src/scalar.rs:27-48) as cheap as the positive ones: their upper windows
+// become zero digits, which are skipped.
+// One product in the signed-digit field (fr30.hip.h) leaves the Montgomery form, reduces and centres at once: the blst_fr
+// image is x * 2^256, times the single digit 2^14 over the multiplier's 2^270 is x; canonical little-endian bytes (expected
+// below r, any 256-bit value accepted) times 2^270 mod r over 2^270 is the value mod r.  The product of balanced
+// Montgomery digits is the centred residue up to r / 2^31 -- which representative is used changes the digits, not the sum.
+// (Two calls: with the multiplier a compile-time constant the first is a reduction and nine shifts, not 162 multiply-adds.)
 KZG_DEV bool load_scalar(const uint32_t* d_scalars, uint64_t i, int is_mont, u32 k[8]) {
     const uint4* p = reinterpret_cast<const uint4*>(d_scalars) + 2 * (size_t)i;
-    uint4 lo = p[0], hi = p[1];
-    Fr a;
-    a.l[0] = lo.x; a.l[1] = lo.y; a.l[2] = lo.z; a.l[3] = lo.w;
-    a.l[4] = hi.x; a.l[5] = hi.y; a.l[6] = hi.z; a.l[7] = hi.w;
-    if (is_mont) {
-        a = fe_from_mont(a);
-    } else {
-        // canonical little-endian bytes are expected below r; reduce defensively (2^256 < 3r)
-        cond_sub_mod(a, 0u);
-        cond_sub_mod(a, 0u);
-    }
-    // neg = r - a ; use it when neg < a  (a > (r-1)/2)
-    u32 nk[8];
-    u32 br = 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++) nk[t] = subb(FrParams::mod(t), a.l[t], br);
-    // compare nk < a : borrow of nk - a
-    u32 b2 = 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++) (void)subb(nk[t], a.l[t], b2);
-    bool flip = b2 != 0;
-#pragma unroll
-    for (int t = 0; t < 8; t++) k[t] = flip ? nk[t] : a.l[t];
-    return flip;
+    const uint4 lo = p[0], hi = p[1];
+    const uint32_t in[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    const Fr30 d = fr30_from_limbs_raw(in);
+    const Fr30 v = is_mont ? fr30_mul(d, fr30_small(1 << 14)) : fr30_mul(d, fr30_const_one270());
+    return fr30_abs_to_limbs(v, k);
 }
 
 // Signed window recoding, low window first: digit in [-2^(c-1)+1, 2^(c-1)], carry into the next

@@ -13,11 +13,15 @@
 //  * trusted setup on the device (reference src/trusted_setup.rs:40-62, G1 side): SRS[i] = [s^i]G1 by
 //    fixed-base windowing over a table of d * 2^(8w) * G1.
 #include "engine.h"
-#include "field.hip.h"  // Fr: the powers of the secret
+#include "fr30.hip.h"  // Fr: the powers of the secret
 #include "field30_inv.hip.h"
 #include "g1_30.hip.h"
 
 namespace kzg {
+
+#ifndef KZG_DEV
+#define KZG_DEV __device__ __forceinline__
+#endif
 
 constexpr int kNormK = 32;  // points per lane in the batched inversion
 
@@ -167,24 +171,26 @@ __global__ void __launch_bounds__(64) k_srs_points(FrArg8 secret, uint64_t first
                                                    const uint4* __restrict__ gtable, uint4* __restrict__ out_xyzz) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    Fr s;
-#pragma unroll
-    for (int t = 0; t < 8; t++) s.l[t] = secret.l[t];
-    s = fe_to_mont(s);  // the secret arrives as the raw 256-bit integer; this also reduces it mod r
+    // the secret arrives as the raw 256-bit integer: times 2^540 over the multiplier's 2^270 it is s * 2^270, reduced
+    // (fr30.hip.h; with that factor on both operands a product keeps it)
+    const Fr30 s = fr30_mul(fr30_from_limbs(secret.l), fr30_const_r2_540());
     // s^(first + i) by square-and-multiply (reference src/trusted_setup.rs:50 walks it sequentially)
     uint64_t e = first + i;
-    Fr pw = Fr::one();
-    Fr base = s;
+    Fr30 pw = fr30_const_one270();
+    Fr30 base = s;
     while (e) {
-        if (e & 1) pw = fe_mul(pw, base);
-        base = fe_mul(base, base);
+        if (e & 1) pw = fr30_mul(pw, base);
+        base = fr30_mul(base, base);
         e >>= 1;
     }
-    Fr k = fe_from_mont(pw);  // canonical scalar, as Scalar::to_le_bytes (src/scalar.rs:83-93)
+    struct {
+        uint32_t l[8];
+    } k;
+    fr30_to_limbs(fr30_mul(pw, fr30_small(1)), k.l);  // canonical scalar, as Scalar::to_le_bytes (src/scalar.rs:83-93)
     XYZZ30 acc = xyzz30_inf();
 #pragma unroll 1
     for (int w = 0; w < kGWindows; w++) {
-        const u32 d = k.l[0] & 0xffu;
+        const uint32_t d = k.l[0] & 0xffu;
 #pragma unroll
         for (int t = 0; t < 7; t++) k.l[t] = (k.l[t] >> 8) | (k.l[t + 1] << 24);
         k.l[7] >>= 8;

@@ -28,6 +28,15 @@ void r30_from_limbs(const uint32_t* l, int32_t* r) {
     Fr30 z = fr30_from_limbs(l);
     memcpy(r, z.d, sizeof z.d);
 }
+void r30_from_limbs_raw(const uint32_t* l, int32_t* r) {
+    Fr30 z = fr30_from_limbs_raw(l);
+    memcpy(r, z.d, sizeof z.d);
+}
+int r30_abs_to_limbs(const int32_t* a, uint32_t* l) {
+    Fr30 x;
+    memcpy(x.d, a, sizeof x.d);
+    return fr30_abs_to_limbs(x, l) ? 1 : 0;
+}
 void r30_to_limbs(const int32_t* a, uint32_t* l) {
     Fr30 x;
     memcpy(x.d, a, sizeof x.d);

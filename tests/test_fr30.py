@@ -54,6 +54,10 @@ def test_constants():
     ru = [0x1, 0x3ffffffc, 0x3fe5bfef, 0x2f6900bf, 0x21d80553, 0x27602026, 0x17d48333, 0x29d4ca67, 0x73ed]
     assert sum(x << (B * i) for i, x in enumerate(ru)) == R
     assert R % (1 << B) == 1  # so -r^-1 = -1 (mod 2^30)
+    one270 = [-0x8d54, 0x23550, -0x21a2ac0, 0x1c22013a, -0x15d0deee, -0x1d3fc534, -0x1dfe7aaf, 0x12b2a695, 0x10dc]
+    r2_540 = [0xefe9ec3, 0x1022c0f, 0x12313d61, 0x83bec60, -0xcc084be, 0x4a39dc, -0x17165989, 0x1dd02cf9, -0xc8f]
+    assert value(one270) % R == pow(2, 270, R) and value(r2_540) % R == pow(2, 540, R)
+    assert all(abs(x) <= 1 << 29 for x in one270[:8] + r2_540[:8])
 
 
 def test_mul_random_lazy_operands(lib):
@@ -112,6 +116,57 @@ def test_to_limbs_canonicalises_the_range_the_scans_hold(lib):
         out = U8()
         lib.r30_to_limbs(I9(*d), out)
         assert list(out) == limbs(v % R), (it, v)
+
+
+def test_leaving_the_montgomery_form_and_raw_integers(lib):
+    """what the scalar recoding and the SRS generator do: x * 2^256 times the single digit 2^14 is x; a raw 256-bit integer
+    times 2^540 mod r is s * 2^270; with that factor on both operands a product keeps it; times the digit 1 drops it"""
+    rng = random.Random(14)
+    one270 = [-0x8d54, 0x23550, -0x21a2ac0, 0x1c22013a, -0x15d0deee, -0x1d3fc534, -0x1dfe7aaf, 0x12b2a695, 0x10dc]
+    r2_540 = [0xefe9ec3, 0x1022c0f, 0x12313d61, 0x83bec60, -0xcc084be, 0x4a39dc, -0x17165989, 0x1dd02cf9, -0xc8f]
+    small = lambda c: I9(*([c] + [0] * 8))
+    for it in range(500):
+        x = rng.choice([0, 1, R - 1]) if it < 3 else rng.randrange(R)
+        d, r, out = I9(), I9(), U8()
+        lib.r30_from_limbs(U8(*limbs((x << 256) % R)), d)
+        lib.r30_mul(d, small(1 << 14), r)
+        lib.r30_to_limbs(r, out)
+        assert list(out) == limbs(x)
+        raw = rng.randrange(1 << 256)  # any 256-bit value
+        lib.r30_from_limbs(U8(*limbs(raw)), d)
+        lib.r30_mul(d, I9(*one270), r)
+        lib.r30_to_limbs(r, out)
+        assert list(out) == limbs(raw % R)
+        s270 = I9()
+        lib.r30_mul(d, I9(*r2_540), s270)
+        assert value(list(s270)) % R == (raw << 270) % R
+        sq, plain = I9(), I9()
+        lib.r30_mul(s270, s270, sq)
+        lib.r30_mul(sq, small(1), plain)
+        lib.r30_to_limbs(plain, out)
+        assert list(out) == limbs(raw * raw % R)
+
+
+def test_sign_and_magnitude_of_the_recoding(lib):
+    """msm_sort.hip's load_scalar: unsigned digits straight into the product, sign and magnitude out; the magnitude times
+    the sign is the scalar (mod r) and stays below 2^254"""
+    rng = random.Random(15)
+    one270 = [-0x8d54, 0x23550, -0x21a2ac0, 0x1c22013a, -0x15d0deee, -0x1d3fc534, -0x1dfe7aaf, 0x12b2a695, 0x10dc]
+    small = lambda c: I9(*([c] + [0] * 8))
+    edge = [0, 1, R - 1, (R - 1) // 2, (R + 1) // 2, (R - 1) // 2 - 1, (R + 1) // 2 + 1, 5, R - 5]
+    for it in range(3000):
+        x = edge[it] if it < len(edge) else rng.randrange(R)
+        for mont in (True, False):
+            image = (x << 256) % R if mont else x + (R if (not mont and it % 7 == 0 and x + R < 1 << 256) else 0)
+            d, v, out = I9(), I9(), U8()
+            lib.r30_from_limbs_raw(U8(*limbs(image)), d)
+            assert all(0 <= t < (1 << 30) for t in list(d)[:8]) and value(list(d)) == image
+            lib.r30_mul(d, small(1 << 14) if mont else I9(*one270), v)
+            neg = lib.r30_abs_to_limbs(v, out)
+            k = sum(w << (32 * i) for i, w in enumerate(out))
+            assert k < 1 << 254 and k <= R // 2 + (R >> 31) + 2
+            assert ((-k if neg else k) - x) % R == 0
+            assert k == abs(value(list(v)))
 
 
 def test_host_prepared_multiplier_keeps_the_abi_form(lib):
