@@ -4,8 +4,9 @@
 // whole polynomial at once.
 //
 // HBM traffic per commitment of n terms, W windows: scalars read twice (2 x 32 B x n), pairs written
-// once and read twice (3 x 8 B x n x W), references written (4 B x n x W).  Integer / byte work bound
-// by LDS atomics and scattered 4..8-byte stores, not by arithmetic.
+// once and read twice (3 x 4 B x n x W in the packed form -- table index below 2^24, e.g. degree 2^20 -- else
+// 3 x 8 B), references written (4 B x n x W).  Integer / byte work bound by LDS atomics and scattered 4..8-byte
+// stores, not by arithmetic.
 #include <cstdlib>
 #include <cstring>
 
@@ -191,36 +192,52 @@ struct SortGeom {
     uint32_t tiles;        // workgroups
     uint32_t fine_bits;    // low bits of the bucket id resolved in pass 3
     uint32_t coarse_bins;  // nb >> fine_bits
+    bool packed;           // pairs are 4 bytes (sign | fine key : 7 | table index : 24) instead of 8
 };
 
-static uint32_t sort_fine_bits(MsmConfig cfg) {
-    uint32_t bits = ilog2(cfg.nb);
-    return bits < 8 ? bits : 8;
+// The (fine key, table reference) pairs of the spread pass are written once and read twice: at 8 bytes each they are
+// the largest stream of the sort.  When the table index fits 24 bits (W * table stride <= 2^24: a degree-2^20 commitment
+// has 15 x (2^20 + 1)) and the buckets split into at most kMaxCoarse bins of 128, a pair is ONE word.
+constexpr uint32_t kPackedFineBits = 7, kPackedIndexBits = 24;
+static uint32_t sort_fine_bits(MsmConfig cfg, bool packed) {
+    const uint32_t bits = ilog2(cfg.nb), most = packed ? kPackedFineBits : 8u;
+    return bits < most ? bits : most;
 }
+static bool sort_packed_buckets(uint32_t nb_total, MsmConfig cfg);
+
+static bool sort_packed_buckets(uint32_t nb_total, MsmConfig cfg) { return (nb_total >> sort_fine_bits(cfg, true)) <= (uint32_t)kMaxCoarse; }
 
 // `total` scalars (batch * n) into `nb_total` buckets (batch * 2^(c-1): polynomial-major bucket ids)
-static SortGeom sort_geometry(uint64_t total, uint32_t nb_total, MsmConfig cfg) {
+static SortGeom sort_geometry(uint64_t total, uint32_t nb_total, MsmConfig cfg, uint32_t table_stride) {
     SortGeom g;
+    static const bool allow_packed = [] { const char* v = std::getenv("KZG_SORT_PACKED"); return !(v && v[0] == '0'); }();
+    g.packed = allow_packed && sort_packed_buckets(nb_total, cfg) && (uint64_t)cfg.W * table_stride <= (1ull << kPackedIndexBits);
     uint32_t tile = (uint32_t)((total + 255) / 256);      // at most 256 tiles (bounds the count table)
     tile = ((tile + kSortBlock - 1) / kSortBlock) * kSortBlock;
     if (tile < (uint32_t)kSortBlock) tile = kSortBlock;
     g.tile = tile;
     g.tiles = (uint32_t)((total + tile - 1) / tile);
-    g.fine_bits = sort_fine_bits(cfg);
+    g.fine_bits = sort_fine_bits(cfg, g.packed);
     g.coarse_bins = nb_total >> g.fine_bits;
     return g;
 }
 
 uint32_t sort_max_batch(MsmConfig cfg) {
-    uint32_t fine_bits = sort_fine_bits(cfg);
+    uint32_t fine_bits = sort_fine_bits(cfg, false);
     uint32_t b = (uint32_t)kMaxCoarse / (cfg.nb >> fine_bits);
     return b < 1 ? 1 : b;
 }
 
 uint32_t sort_count_entries(uint32_t max_batch, MsmConfig cfg) {
     // coarse bins x tiles, tiles bounded by 256 (+1) whatever the length of the commitment
-    uint32_t fine_bits = sort_fine_bits(cfg);
-    return ((cfg.nb * max_batch) >> fine_bits) * 257u;
+    // (the largest bin count any batch <= max_batch can have: small batches take the packed form, with twice the bins)
+    uint32_t bins = 0;
+    for (uint32_t b = 1; b <= max_batch; b++) {
+        const uint32_t nbt = cfg.nb * b;
+        const uint32_t q = nbt >> sort_fine_bits(cfg, sort_packed_buckets(nbt, cfg));
+        if (q > bins) bins = q;
+    }
+    return bins * 257u;
 }
 
 // Batch addressing shared by passes 1 and 2: global scalar index g -> polynomial p = g / n, term i = g % n;
@@ -286,7 +303,7 @@ __global__ void __launch_bounds__(kRecodeBlock) k_sort_spread(const uint32_t* __
                                                             const uint32_t* __restrict__ d_binfill /* bin totals */,
                                                             uint32_t ch, uint32_t* __restrict__ d_binstart,
                                                             uint32_t* __restrict__ d_prefix, uint32_t* __restrict__ d_total,
-                                                            uint64_t* __restrict__ d_pairs) {
+                                                            uint64_t* __restrict__ d_pairs, int packed) {
     __shared__ u32 s_cur[kMaxCoarse];
     __shared__ u32 s_scan[kRecodeBlock];
     const uint32_t t = threadIdx.x;
@@ -343,7 +360,8 @@ __global__ void __launch_bounds__(kRecodeBlock) k_sort_spread(const uint32_t* __
             u32 b = pb + bkt;
             u32 pos = atomicAdd(&s_cur[b >> fine_bits], 1u);
             u32 ref = (j * table_stride + i) | ((neg != flip) ? 0x80000000u : 0u);
-            d_pairs[pos] = ((uint64_t)(b & fine_mask) << 32) | ref;
+            if (packed) reinterpret_cast<u32*>(d_pairs)[pos] = ref | ((b & fine_mask) << kPackedIndexBits);
+            else d_pairs[pos] = ((uint64_t)(b & fine_mask) << 32) | ref;
         });
     }
 }
@@ -391,7 +409,21 @@ KZG_DEV bool locate_chunk(uint32_t k, const uint32_t* __restrict__ d_prefix, con
     return true;
 }
 
-__global__ void __launch_bounds__(kSortBlock) k_fine_count(const uint64_t* __restrict__ d_pairs,
+// a pair in either form: its fine key and the reference that goes out (sign | table index)
+template <bool kPacked> struct SortPair;
+template <> struct SortPair<false> {
+    typedef uint64_t type;
+    static KZG_DEV u32 key(uint64_t p) { return (u32)(p >> 32); }
+    static KZG_DEV u32 ref(uint64_t p) { return (u32)p; }
+};
+template <> struct SortPair<true> {
+    typedef uint32_t type;
+    static KZG_DEV u32 key(uint32_t p) { return (p >> kPackedIndexBits) & ((1u << kPackedFineBits) - 1u); }
+    static KZG_DEV u32 ref(uint32_t p) { return p & (0x80000000u | ((1u << kPackedIndexBits) - 1u)); }
+};
+
+template <bool kPacked>
+__global__ void __launch_bounds__(kSortBlock) k_fine_count(const typename SortPair<kPacked>::type* __restrict__ d_pairs,
                                                            const uint32_t* __restrict__ d_binstart, uint32_t fine_bits,
                                                            uint32_t coarse_bins, uint32_t ch,
                                                            const uint32_t* __restrict__ d_prefix,
@@ -405,7 +437,7 @@ __global__ void __launch_bounds__(kSortBlock) k_fine_count(const uint64_t* __res
     const uint32_t fine = 1u << fine_bits;
     if (threadIdx.x < fine) s_hist[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t e = c.beg + threadIdx.x; e < c.end; e += kSortBlock) atomicAdd(&s_hist[(u32)(d_pairs[e] >> 32)], 1u);
+    for (uint32_t e = c.beg + threadIdx.x; e < c.end; e += kSortBlock) atomicAdd(&s_hist[SortPair<kPacked>::key(d_pairs[e])], 1u);
     __syncthreads();
     if (threadIdx.x < fine) d_table[(size_t)c.base * fine + (size_t)threadIdx.x * c.nch + c.j] = s_hist[threadIdx.x];
 }
@@ -447,7 +479,8 @@ __global__ void __launch_bounds__(kSortBlock) k_fine_binscan(const uint32_t* __r
 // memory, so a wave's 64 stores fall into a handful of 64-byte runs instead of 64 different ones (the direct form
 // issued 15.7 M separate 4-byte store transactions per commitment: 145 us alone at 2^20 terms).
 constexpr uint32_t kFineStage = 4096;  // references staged per round (16 KB + 16 KB of LDS)
-__global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const uint64_t* __restrict__ d_pairs,
+template <bool kPacked>
+__global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const typename SortPair<kPacked>::type* __restrict__ d_pairs,
                                                              const uint32_t* __restrict__ d_binstart,
                                                              uint32_t fine_bits, uint32_t coarse_bins, uint32_t ch,
                                                              const uint32_t* __restrict__ d_prefix,
@@ -493,12 +526,12 @@ __global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const uint64_t* __r
         if (t < kFineMax) s_cnt[t] = 0;
         __syncthreads();
         // pass 1: count per key inside the round (pairs stay in registers: kFineStage / kSortBlock = 16 per lane)
-        uint64_t pr[kFineStage / kSortBlock];
+        typename SortPair<kPacked>::type pr[kFineStage / kSortBlock];
 #pragma unroll
         for (uint32_t q = 0; q < kFineStage / kSortBlock; q++) {
             const uint32_t e = r0 + q * kSortBlock + t;
-            pr[q] = e < r1 ? d_pairs[e] : ~0ull;
-            if (e < r1) atomicAdd(&s_cnt[(u32)(pr[q] >> 32)], 1u);
+            pr[q] = e < r1 ? d_pairs[e] : (typename SortPair<kPacked>::type)0;
+            if (e < r1) atomicAdd(&s_cnt[SortPair<kPacked>::key(pr[q])], 1u);
         }
         __syncthreads();
         // exclusive scan of the (at most 256) counts: one lane per key, Hillis-Steele in LDS
@@ -534,7 +567,7 @@ __global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const uint64_t* __r
         for (uint32_t q = 0; q < kFineStage / kSortBlock; q++) {
             const uint32_t e = r0 + q * kSortBlock + t;
             if (e < r1) {
-                const u32 key = (u32)(pr[q] >> 32);
+                const u32 key = SortPair<kPacked>::key(pr[q]);
                 const u32 pos = atomicAdd(&s_cnt[key], 1u);
                 keep_pos[q] = pos;
                 keep_dst[q] = s_dst[key] + pos;
@@ -545,7 +578,7 @@ __global__ void __launch_bounds__(kSortBlock) k_fine_scatter(const uint64_t* __r
         for (uint32_t q = 0; q < kFineStage / kSortBlock; q++) {
             const uint32_t e = r0 + q * kSortBlock + t;
             if (e < r1) {
-                s_ref[keep_pos[q]] = (u32)pr[q];
+                s_ref[keep_pos[q]] = SortPair<kPacked>::ref(pr[q]);
                 s_dst[keep_pos[q]] = keep_dst[q];
             }
         }
@@ -656,7 +689,7 @@ bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, u
         return true;
     }
     const uint32_t nb_total = cfg.nb * batch;
-    SortGeom g = sort_geometry((uint64_t)n * batch, nb_total, cfg);
+    SortGeom g = sort_geometry((uint64_t)n * batch, nb_total, cfg, table_stride);
     BatchGeom bg{n, batch, stride, cfg.nb};
     uint32_t* d_binstart = d_ws + kWsBinStart;
     uint32_t* d_prefix = d_ws + kWsPrefix;
@@ -669,12 +702,21 @@ bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, u
     hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kRecodeBlock), 0, s, d_scalars, is_mont, bg, cfg, g.tile,
                        g.fine_bits, g.coarse_bins, d_cnt, d_binfill, d_header);
     hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kRecodeBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg,
-                       g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_binfill, ch, d_binstart, d_prefix, d_total, d_pairs);
-    hipLaunchKernelGGL(k_fine_count, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_binstart, g.fine_bits,
-                       g.coarse_bins, ch, d_prefix, d_table, d_binfill);
+                       g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_binfill, ch, d_binstart, d_prefix, d_total, d_pairs,
+                       g.packed ? 1 : 0);
+    if (g.packed)
+        hipLaunchKernelGGL(k_fine_count<true>, dim3(max_chunks), dim3(kSortBlock), 0, s, reinterpret_cast<const uint32_t*>(d_pairs),
+                           d_binstart, g.fine_bits, g.coarse_bins, ch, d_prefix, d_table, d_binfill);
+    else
+        hipLaunchKernelGGL(k_fine_count<false>, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_binstart, g.fine_bits,
+                           g.coarse_bins, ch, d_prefix, d_table, d_binfill);
     hipLaunchKernelGGL(k_fine_binscan, dim3(g.coarse_bins), dim3(kSortBlock), 0, s, d_binstart, g.fine_bits, d_prefix, d_table, d_offs);
-    hipLaunchKernelGGL(k_fine_scatter, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_binstart, g.fine_bits,
-                       g.coarse_bins, ch, d_prefix, d_table, d_offs, d_sorted);
+    if (g.packed)
+        hipLaunchKernelGGL(k_fine_scatter<true>, dim3(max_chunks), dim3(kSortBlock), 0, s, reinterpret_cast<const uint32_t*>(d_pairs),
+                           d_binstart, g.fine_bits, g.coarse_bins, ch, d_prefix, d_table, d_offs, d_sorted);
+    else
+        hipLaunchKernelGGL(k_fine_scatter<false>, dim3(max_chunks), dim3(kSortBlock), 0, s, d_pairs, d_binstart, g.fine_bits,
+                           g.coarse_bins, ch, d_prefix, d_table, d_offs, d_sorted);
     return true;
 }
 
