@@ -220,7 +220,7 @@ def batch_of_openings(eng, limbs, n, degree, golden, dev, torch, np, K):
     return {"openings_batch8_per_sec": 8.0 / dt, "openings_batch8_ms": dt * 1e3,
             "openings_batch8_host_pointer_per_sec": 8.0 / dth,
             "openings_batch8_note": "config 5's per-GPU share: 8 x degree-2^20 openings in one kzg_open_batch_submit, resident inputs; "
-                                    "host_pointer: the same through kzg_open_batch (PCIe copies inside, sub-batches of 2 pipelined through the slots)"}
+                                    "host_pointer: the same through kzg_open_batch (PCIe copies inside, one polynomial per stream slot at this size)"}
 
 
 def main():
