@@ -177,13 +177,19 @@ KZG_DEV void for_each_digit(u32 k[8], MsmConfig cfg, F&& f) {
 //   fine scatter chunk (bin, j): positions from H -- for ordinary bins computed on the spot from the bin's own
 //                <= 256 x 16 entries -- then the references are moved to their final, bucket-major position (below);
 //                chunk 0 of a bin writes the bin's bucket offsets
-// No global atomics, no rank array; order inside a bucket is arbitrary (the group law is commutative,
+// No global atomic per reference (one per tile and bin), no rank array; order inside a bucket is arbitrary (the group law is commutative,
 // the result is bit-identical).
 constexpr int kSortBlock = 256;
-// The two recoding passes run 1024 lanes per workgroup: a tile is one workgroup (at most 256 tiles bound the offset table),
+// The two recoding passes run 1024 lanes per workgroup (512 in the staged form of the second): a tile is one workgroup,
 // and with 256 lanes a CU held ONE wave per SIMD walking 16 scalars one after the other -- load, from-Montgomery
 // product, 15 LDS atomics -- with nothing to hide the loads behind (54 + 85 us at 2^20).
 constexpr int kRecodeBlock = 1024;
+// Tiles (= workgroups of the two recoding passes) per job, at most: they bound the offset table [tile][bin].  512 puts two
+// workgroups on every CU (256: 35 + 87 us for the two passes at 2^20, 512: 35 + 69, 1024: 41 + 78).
+#ifndef KZG_SORT_TILES
+#define KZG_SORT_TILES 512
+#endif
+constexpr uint32_t kMaxTiles = KZG_SORT_TILES;
 constexpr int kMaxCoarse = 2048;
 constexpr int kFineMax = 256;
 
@@ -212,7 +218,7 @@ static SortGeom sort_geometry(uint64_t total, uint32_t nb_total, MsmConfig cfg, 
     SortGeom g;
     static const bool allow_packed = [] { const char* v = std::getenv("KZG_SORT_PACKED"); return !(v && v[0] == '0'); }();
     g.packed = allow_packed && sort_packed_buckets(nb_total, cfg) && (uint64_t)cfg.W * table_stride <= (1ull << kPackedIndexBits);
-    uint32_t tile = (uint32_t)((total + 255) / 256);      // at most 256 tiles (bounds the count table)
+    uint32_t tile = (uint32_t)((total + kMaxTiles - 1) / kMaxTiles);  // at most kMaxTiles tiles (bounds the count table)
     tile = ((tile + kSortBlock - 1) / kSortBlock) * kSortBlock;
     if (tile < (uint32_t)kSortBlock) tile = kSortBlock;
     g.tile = tile;
@@ -237,7 +243,7 @@ uint32_t sort_count_entries(uint32_t max_batch, MsmConfig cfg) {
         const uint32_t q = nbt >> sort_fine_bits(cfg, sort_packed_buckets(nbt, cfg));
         if (q > bins) bins = q;
     }
-    return bins * 257u;
+    return bins * (kMaxTiles + 1u);
 }
 
 // Batch addressing shared by passes 1 and 2: global scalar index g -> polynomial p = g / n, term i = g % n;
@@ -296,40 +302,35 @@ constexpr uint32_t kWsTable = 3 * kMaxCoarse + 64;   // H
 uint32_t sort_workspace_words() { return kWsTable + kFineMaxChunks * (uint32_t)kFineMax + 64; }
 uint32_t sort_workspace_zero_words() { return kWsTable; }  // what the owner clears once, when it allocates the workspace
 
-__global__ void __launch_bounds__(kRecodeBlock) k_sort_spread(const uint32_t* __restrict__ d_scalars, int is_mont,
-                                                            BatchGeom bg, uint32_t table_stride, MsmConfig cfg,
-                                                            uint32_t tile, uint32_t tiles, uint32_t fine_bits,
-                                                            uint32_t coarse_bins, const uint32_t* __restrict__ d_cnt /* [tile][bin] */,
-                                                            const uint32_t* __restrict__ d_binfill /* bin totals */,
-                                                            uint32_t ch, uint32_t* __restrict__ d_binstart,
-                                                            uint32_t* __restrict__ d_prefix, uint32_t* __restrict__ d_total,
-                                                            uint64_t* __restrict__ d_pairs, int packed) {
-    __shared__ u32 s_cur[kMaxCoarse];
-    __shared__ u32 s_scan[kRecodeBlock];
+// cursors of a tile: start of every bin (exclusive scan of the bin totals, <= 2048 values, in LDS) + the offset the tile took
+// inside the bin (k_sort_count).  Thread t handles the bins t + BLOCK s.  Workgroup 0 also leaves what the fine passes need:
+// the bin starts and their chunk plan.
+template <int BLOCK>
+KZG_DEV void spread_tile_cursors(uint32_t coarse_bins, const uint32_t* __restrict__ d_cnt, const uint32_t* __restrict__ d_binfill,
+                                 uint32_t ch, uint32_t* __restrict__ d_binstart, uint32_t* __restrict__ d_prefix,
+                                 uint32_t* __restrict__ d_total, u32* s_cur /* kMaxCoarse */, u32* s_scan /* BLOCK */) {
     const uint32_t t = threadIdx.x;
-    // cursors of this tile: start of the bin (exclusive scan of the bin totals, <= 2048 values, in LDS) + the offset
-    // the tile took inside the bin (k_sort_count).  Thread t handles the bins t + 1024 s.
-    constexpr uint32_t kStripes = kMaxCoarse / kRecodeBlock;
+    constexpr uint32_t kStripes = kMaxCoarse / BLOCK;
     u32 below[kStripes], all[kStripes];
 #pragma unroll
     for (uint32_t s = 0; s < kStripes; s++) {
-        const uint32_t q = t + s * kRecodeBlock;
+        const uint32_t q = t + s * BLOCK;
         all[s] = q < coarse_bins ? d_binfill[q] : 0u;
         below[s] = q < coarse_bins ? d_cnt[(size_t)blockIdx.x * coarse_bins + q] : 0u;
     }
     u32 carry = 0, chunk_carry = 0;
 #pragma unroll
     for (uint32_t s = 0; s < kStripes; s++) {
-        if (s * kRecodeBlock >= coarse_bins) break;  // (uniform)
-        const uint32_t q = t + s * kRecodeBlock;
+        if (s * BLOCK >= coarse_bins) break;  // (uniform)
+        const uint32_t q = t + s * BLOCK;
         u32 stripe_total;
-        const u32 start = carry + block_exclusive_scan_n<kRecodeBlock>(all[s], s_scan, stripe_total);
+        const u32 start = carry + block_exclusive_scan_n<BLOCK>(all[s], s_scan, stripe_total);
         __syncthreads();
         if (q < coarse_bins) s_cur[q] = start + below[s];
-        if (blockIdx.x == 0) {  // what the fine passes need: bin starts and their chunk plan
+        if (blockIdx.x == 0) {
             const u32 nch = q < coarse_bins ? (all[s] + ch - 1) / ch : 0u;
             u32 chunk_total;
-            const u32 cstart = chunk_carry + block_exclusive_scan_n<kRecodeBlock>(nch, s_scan, chunk_total);
+            const u32 cstart = chunk_carry + block_exclusive_scan_n<BLOCK>(nch, s_scan, chunk_total);
             __syncthreads();
             if (q < coarse_bins) {
                 d_binstart[q] = start;
@@ -345,6 +346,19 @@ __global__ void __launch_bounds__(kRecodeBlock) k_sort_spread(const uint32_t* __
         *d_total = carry;
     }
     __syncthreads();
+}
+
+__global__ void __launch_bounds__(kRecodeBlock) k_sort_spread(const uint32_t* __restrict__ d_scalars, int is_mont,
+                                                            BatchGeom bg, uint32_t table_stride, MsmConfig cfg,
+                                                            uint32_t tile, uint32_t tiles, uint32_t fine_bits,
+                                                            uint32_t coarse_bins, const uint32_t* __restrict__ d_cnt /* [tile][bin] */,
+                                                            const uint32_t* __restrict__ d_binfill /* bin totals */,
+                                                            uint32_t ch, uint32_t* __restrict__ d_binstart,
+                                                            uint32_t* __restrict__ d_prefix, uint32_t* __restrict__ d_total,
+                                                            uint64_t* __restrict__ d_pairs, int packed) {
+    __shared__ u32 s_cur[kMaxCoarse];
+    __shared__ u32 s_scan[kRecodeBlock];
+    spread_tile_cursors<kRecodeBlock>(coarse_bins, d_cnt, d_binfill, ch, d_binstart, d_prefix, d_total, s_cur, s_scan);
     const uint64_t base = (uint64_t)blockIdx.x * tile;
     const uint64_t total = (uint64_t)bg.n * bg.batch;
     const u32 fine_mask = (1u << fine_bits) - 1u;
@@ -363,6 +377,121 @@ __global__ void __launch_bounds__(kRecodeBlock) k_sort_spread(const uint32_t* __
             if (packed) reinterpret_cast<u32*>(d_pairs)[pos] = ref | ((b & fine_mask) << kPackedIndexBits);
             else d_pairs[pos] = ((uint64_t)(b & fine_mask) << 32) | ref;
         });
+    }
+}
+
+// ---- the spread pass staged through LDS (one-word pairs) ---------------------------------------------------------------
+// The direct form above issues one 4-byte store per digit, each lane of a wave into a different bin: 15.7 M store
+// transactions per degree-2^20 commitment (84 us whether a pair is 4 or 8 bytes, and however many tiles there are).  Here a
+// workgroup takes its tile in rounds of kStageBlock scalars: the round's pairs are counted per bin (LDS atomics), the counts
+// scanned, the pairs placed bin-major into an LDS buffer (the atomics' return values are the slots), and written out by
+// consecutive lanes -- a bin's pairs of one round are contiguous in the bin (the tile's range inside it is), so a wave's 64
+// stores fall into a few runs instead of 64 places.  The digits are cut twice per round (the scalar itself is converted
+// once); order inside a bin is arbitrary as before.  69 us at 2^20 with two workgroups per CU (87 with one: a round is a
+// chain of a global load, a product and two passes of LDS atomics, and eight waves per CU do not hide it).
+constexpr int kStageBlock = 512;
+constexpr uint32_t kStageSlots = 7680;  // pairs per round: 512 scalars x 15 digits (fewer scalars per round when a scalar has more)
+
+// exclusive scan of one value per thread: shuffles inside the wave, the wave totals through LDS (two barriers)
+template <int BLOCK>
+KZG_DEV u32 block_exclusive_scan_fast(u32 v, u32* s_wave /* BLOCK / 64 */, u32& total) {
+    const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+    u32 incl = v;
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const u32 up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[w] = incl;
+    __syncthreads();
+    u32 base = 0, all = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < BLOCK / 64; i++) {
+        const u32 x = s_wave[i];
+        if (i < w) base += x;
+        all += x;
+    }
+    __syncthreads();
+    total = all;
+    return base + incl - v;
+}
+
+__global__ void __launch_bounds__(kStageBlock) k_sort_spread_staged(const uint32_t* __restrict__ d_scalars, int is_mont,
+                                                                  BatchGeom bg, uint32_t table_stride, MsmConfig cfg,
+                                                                  uint32_t tile, uint32_t fine_bits, uint32_t coarse_bins,
+                                                                  const uint32_t* __restrict__ d_cnt, const uint32_t* __restrict__ d_binfill,
+                                                                  uint32_t ch, uint32_t* __restrict__ d_binstart,
+                                                                  uint32_t* __restrict__ d_prefix, uint32_t* __restrict__ d_total,
+                                                                  uint32_t* __restrict__ d_pairs32) {
+    __shared__ u32 s_cur[kMaxCoarse];    // the tile's cursor in every bin (global position of its next pair)
+    __shared__ u32 s_cnt[kMaxCoarse];    // round: pairs per bin, then the bins' cursors inside the staging buffer
+    __shared__ u32 s_gd[kMaxCoarse];     // round: global position minus staging slot, per bin
+    __shared__ u32 s_scan[kStageBlock];
+    __shared__ u32 s_stage[kStageSlots];
+    __shared__ uint16_t s_sbin[kStageSlots];
+    spread_tile_cursors<kStageBlock>(coarse_bins, d_cnt, d_binfill, ch, d_binstart, d_prefix, d_total, s_cur, s_scan);
+    const uint32_t t = threadIdx.x;
+    const uint64_t base = (uint64_t)blockIdx.x * tile;
+    const uint64_t total = (uint64_t)bg.n * bg.batch;
+    const u32 fine_mask = (1u << fine_bits) - 1u;
+    const uint32_t per_round = kStageSlots / cfg.max_digits < (uint32_t)kStageBlock ? kStageSlots / cfg.max_digits : (uint32_t)kStageBlock;
+    constexpr uint32_t kBinsPerLane = kMaxCoarse / kStageBlock;  // lane t owns the bins [t * kBinsPerLane, ...) in the scan
+    for (uint32_t r0 = 0; r0 < tile; r0 += per_round) {
+        for (uint32_t q = t; q < coarse_bins; q += kStageBlock) s_cnt[q] = 0;
+        __syncthreads();
+        const uint32_t off = r0 + t;
+        const uint64_t g = base + off;
+        const bool valid = t < per_round && off < tile && g < total;
+        u32 k[8];
+        bool flip = false;
+        uint32_t i = 0;
+        u32 pb = 0;
+        if (valid) {
+            const uint32_t p = (uint32_t)(g / bg.n);
+            i = (uint32_t)(g - (uint64_t)p * bg.n);
+            pb = p * bg.nb;
+            flip = load_scalar(d_scalars, p * bg.stride + i, is_mont, k);
+            u32 k1[8];
+#pragma unroll
+            for (int w = 0; w < 8; w++) k1[w] = k[w];
+            for_each_digit(k1, cfg, [&](uint32_t, u32 bkt, bool) { atomicAdd(&s_cnt[(pb + bkt) >> fine_bits], 1u); });
+        }
+        __syncthreads();
+        // scan of the round's counts: lane t sums its kBinsPerLane consecutive bins, the sums are scanned, then every bin gets
+        // its first staging slot; the tile's cursor advances by the round's pairs
+        u32 mine[kBinsPerLane], sum = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < kBinsPerLane; e++) {
+            const uint32_t q = t * kBinsPerLane + e;
+            mine[e] = q < coarse_bins ? s_cnt[q] : 0u;
+            sum += mine[e];
+        }
+        u32 round_total;
+        u32 run = block_exclusive_scan_fast<kStageBlock>(sum, s_scan, round_total);
+#pragma unroll
+        for (uint32_t e = 0; e < kBinsPerLane; e++) {
+            const uint32_t q = t * kBinsPerLane + e;
+            if (q < coarse_bins) {
+                const u32 cur = s_cur[q];
+                s_gd[q] = cur - run;
+                s_cur[q] = cur + mine[e];
+                s_cnt[q] = run;
+            }
+            run += mine[e];
+        }
+        __syncthreads();
+        if (valid) {
+            for_each_digit(k, cfg, [&](uint32_t j, u32 bkt, bool neg) {
+                const u32 b = pb + bkt, bin = b >> fine_bits;
+                const u32 slot = atomicAdd(&s_cnt[bin], 1u);
+                s_stage[slot] = (j * table_stride + i) | ((neg != flip) ? 0x80000000u : 0u) | ((b & fine_mask) << kPackedIndexBits);
+                s_sbin[slot] = (uint16_t)bin;
+            });
+        }
+        __syncthreads();
+        for (uint32_t e = t; e < round_total; e += kStageBlock) d_pairs32[s_gd[s_sbin[e]] + e] = s_stage[e];
+        // (no barrier here: the next round's first barrier stands between these reads and its writes of s_gd / s_stage / s_sbin;
+        // s_cnt, which it clears before that barrier, is not read above)
     }
 }
 
@@ -701,9 +830,15 @@ bool launch_bucket_sort(hipStream_t s, const uint32_t* d_scalars, int is_mont, u
     uint32_t* d_binfill = d_ws + kWsBinFill;
     hipLaunchKernelGGL(k_sort_count, dim3(g.tiles), dim3(kRecodeBlock), 0, s, d_scalars, is_mont, bg, cfg, g.tile,
                        g.fine_bits, g.coarse_bins, d_cnt, d_binfill, d_header);
-    hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kRecodeBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg,
-                       g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_binfill, ch, d_binstart, d_prefix, d_total, d_pairs,
-                       g.packed ? 1 : 0);
+    static const bool staged = [] { const char* v = std::getenv("KZG_SPREAD_STAGED"); return !(v && v[0] == '0'); }();
+    if (g.packed && staged && cfg.max_digits <= kStageSlots)
+        hipLaunchKernelGGL(k_sort_spread_staged, dim3(g.tiles), dim3(kStageBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg,
+                           g.tile, g.fine_bits, g.coarse_bins, d_cnt, d_binfill, ch, d_binstart, d_prefix, d_total,
+                           reinterpret_cast<uint32_t*>(d_pairs));
+    else
+        hipLaunchKernelGGL(k_sort_spread, dim3(g.tiles), dim3(kRecodeBlock), 0, s, d_scalars, is_mont, bg, table_stride, cfg,
+                           g.tile, g.tiles, g.fine_bits, g.coarse_bins, d_cnt, d_binfill, ch, d_binstart, d_prefix, d_total, d_pairs,
+                           g.packed ? 1 : 0);
     if (g.packed)
         hipLaunchKernelGGL(k_fine_count<true>, dim3(max_chunks), dim3(kSortBlock), 0, s, reinterpret_cast<const uint32_t*>(d_pairs),
                            d_binstart, g.fine_bits, g.coarse_bins, ch, d_prefix, d_table, d_binfill);
