@@ -13,8 +13,8 @@
 // x (91 + 13^2), and R (Q - X3) - Y1 PPP as two digit products under one reduction) + ~1400 other VALU instructions,
 // against one 128-byte table record gathered by LDS-DMA + 4 B of reference; it runs within ~10 % of the sum of the two pipe
 // times of that mix (measured bare-loop rates), at two waves per SIMD as well as at three -- a three-wave form of the kernel
-// (no exceptional branches, 163 VGPRs, no spills) measured 2354 us against 2336 us (DESIGN.md section 4.4,
-// profiles/r03_accum_isa_histogram.txt).
+// (no exceptional branches, 163 VGPRs, no spills) measured 2354 us against 2336 us alone, and a build of which three
+// workgroups fit a CU is SLOWER in the pipeline (profiles/r03_accum_isa_histogram.txt).
 // Algorithmic HBM bytes per commitment are those of SURVEY.md section 8(d): 128 B x n + 144 B.
 #include <cstdlib>
 
@@ -91,8 +91,21 @@ __device__ __forceinline__ void accum_issue_gather(const uint4* __restrict__ tab
                                          (__attribute__((address_space(3))) void*)(lds_char_ptr)(uintptr_t)(slot + 1024u * k),
                                          16, 0, 0);
 }
-__device__ __forceinline__ Affine30 accum_take_point(uint32_t slot) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces (and the reference load behind them)
+// kFlushOps: vector-memory operations a bucket flush issues between the gather and this wait (accum_flush_run's sixteen
+// stores + the read of the next bucket's end).  The counter is in order: "at most kFlushOps outstanding" means the gather and
+// the reference load in front of them have landed, without waiting for a store's round trip to come back (+2 % at degree
+// 2^20, where one iteration in four of a wave has a lane at a bucket's end).  A SMALLER number of operations on that path
+// would make the wait too weak (the point would be read before it has arrived): tests/test_accum_isa.py counts them in
+// the compiler's output.  (The walk over empty buckets waits for everything inside its loop, so behind it the number is
+// smaller and the gather has landed anyway.)
+constexpr int kFlushOps = 17;
+static_assert(kFlushOps == 17, "the literal in accum_take_point's s_waitcnt");
+__device__ __forceinline__ Affine30 accum_take_point(uint32_t slot, bool wave_flushed = false) {
+#ifdef KZG_ACCUM_FULL_WAIT  // (A/B: wait for the flush too)
+    wave_flushed = false;
+#endif
+    if (wave_flushed) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the DMA pieces (and the reference load behind them)
     Affine30 r;
     lds_u4_ptr q = (lds_u4_ptr)(uintptr_t)(slot + accum_wave_lane() * 16u);
     const accum_u32x4 x0 = q[0], x1 = q[64], x2 = q[128], x3 = q[192];
@@ -107,6 +120,40 @@ __device__ __forceinline__ Affine30 accum_take_point(uint32_t slot) {
     r.y.d[12] = (int32_t)y3.x;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot may be overwritten from here on
     return r;
+}
+// A finished run leaves the lane: exactly SIXTEEN 16-byte stores, issued as one block the compiler neither splits, merges nor
+// counts (store_xyzz30 compiles to 17 of mixed widths today; accum_take_point's wait depends on the number).
+__device__ __forceinline__ void accum_flush_run(uint4* dst, const XYZZ30& a) {
+    const Fq* f[4] = {&a.X, &a.Y, &a.ZZ, &a.ZZZ};
+    accum_u32x4 v[16];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        v[4 * c + 0] = accum_u32x4{(uint32_t)f[c]->d[0], (uint32_t)f[c]->d[1], (uint32_t)f[c]->d[2], (uint32_t)f[c]->d[3]};
+        v[4 * c + 1] = accum_u32x4{(uint32_t)f[c]->d[4], (uint32_t)f[c]->d[5], (uint32_t)f[c]->d[6], (uint32_t)f[c]->d[7]};
+        v[4 * c + 2] = accum_u32x4{(uint32_t)f[c]->d[8], (uint32_t)f[c]->d[9], (uint32_t)f[c]->d[10], (uint32_t)f[c]->d[11]};
+        v[4 * c + 3] = accum_u32x4{(uint32_t)f[c]->d[12], 0u, 0u, 0u};
+    }
+    asm volatile(
+        "global_store_dwordx4 %0, %1, off\n\t"
+        "global_store_dwordx4 %0, %2, off offset:16\n\t"
+        "global_store_dwordx4 %0, %3, off offset:32\n\t"
+        "global_store_dwordx4 %0, %4, off offset:48\n\t"
+        "global_store_dwordx4 %0, %5, off offset:64\n\t"
+        "global_store_dwordx4 %0, %6, off offset:80\n\t"
+        "global_store_dwordx4 %0, %7, off offset:96\n\t"
+        "global_store_dwordx4 %0, %8, off offset:112\n\t"
+        "global_store_dwordx4 %0, %9, off offset:128\n\t"
+        "global_store_dwordx4 %0, %10, off offset:144\n\t"
+        "global_store_dwordx4 %0, %11, off offset:160\n\t"
+        "global_store_dwordx4 %0, %12, off offset:176\n\t"
+        "global_store_dwordx4 %0, %13, off offset:192\n\t"
+        "global_store_dwordx4 %0, %14, off offset:208\n\t"
+        "global_store_dwordx4 %0, %15, off offset:224\n\t"
+        "global_store_dwordx4 %0, %16, off offset:240"
+        :
+        : "v"(dst), "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]), "v"(v[4]), "v"(v[5]), "v"(v[6]), "v"(v[7]), "v"(v[8]), "v"(v[9]),
+          "v"(v[10]), "v"(v[11]), "v"(v[12]), "v"(v[13]), "v"(v[14]), "v"(v[15])
+        : "memory");
 }
 // sorted[i] with a 32-bit byte offset on the scalar base (the references of one job are < 2^30)
 __device__ __forceinline__ uint32_t accum_ref(const uint32_t* __restrict__ sorted, uint32_t i) {
@@ -123,6 +170,12 @@ k_bucket_accumulate(const uint4* __restrict__ table, const uint32_t* __restrict_
     // clk (may be null): two zeroed words that receive max(~start) and max(end) over the waves of the launch, in ticks
     // of the constant 100 MHz clock -- the kernel's own duration, measured without a stream event on either side of it
     // (events between consecutive accumulation kernels cost the pipeline 8-10 %)
+    // At most TWO workgroups of this kernel per CU, by register count (the clobber reserves v0..v175: 2 x 176 of the 512
+    // registers of a SIMD lane fit, 3 do not).  The grid is exactly two workgroups per CU; a build that fits three (<= 168
+    // VGPRs) lets the dispatcher stack three on the CUs that are free when the launch begins -- beside the light kernels of
+    // the other slots some always are busy -- and the launch then lasts as long as its most crowded CU: 2.96 ms instead of
+    // 2.32 in the pipeline, with the same 2.29 ms alone.
+    asm volatile("" ::: "v175");
     const bool stamp = clk != nullptr && (threadIdx.x & 63) == 0;
     if (stamp) atomicMax(&clk[0], ~(unsigned long long)wall_clock64());
     const uint32_t lane = blockIdx.x * kAccumBlock + threadIdx.x;
@@ -148,13 +201,15 @@ k_bucket_accumulate(const uint4* __restrict__ table, const uint32_t* __restrict_
     uint32_t ref_next = accum_ref(sorted, min(start + 1, M - 1));
     accum_issue_gather(table, wave_slot, ref);
     for (uint32_t e = start; e < end; e++) {
+        // (wave-uniform: the flush below is issued for the wave when ANY lane is at a bucket's end)
+        const bool wave_flushed = __builtin_amdgcn_ballot_w64(e == b_end) != 0;
         if (e == b_end) {
             // bucket b ends here: flush its run and move to the bucket that owns e (skipping empties)
             uint4* dst = (run_start == b_beg) ? buckets + (size_t)b * kXyzzU4 : part_a + (size_t)lane * kXyzzU4;
-            store_xyzz30(dst, acc);  // a run that began inside the bucket necessarily began at `start`
+            accum_flush_run(dst, acc);  // a run that began inside the bucket necessarily began at `start`
             acc = xyzz30_inf();
             // the end of the next bucket was read one boundary ago: the walk does not wait for memory unless it has
-            // to skip empty buckets
+            // to skip empty buckets (then its own waits take the stores above with them: rare)
             b++;
             b_beg = b_end;
             b_end = b_end_next;
@@ -169,7 +224,10 @@ k_bucket_accumulate(const uint4* __restrict__ table, const uint32_t* __restrict_
         Fq P, R;
         bool more;
         {
-            const Affine30 p = accum_take_point(wave_slot);
+            // After a flush the wait lets the flush's own kFlushOps operations stay in flight: without that every bucket
+            // boundary in a wave -- one iteration in four at degree 2^20, nine in ten in a batch of short polynomials --
+            // stood still for a store's round trip before it looked at its point.
+            const Affine30 p = accum_take_point(wave_slot, wave_flushed);
             more = xyzz30_madd_head(acc, p, (ref >> 31) != 0, P, R);
         }
         // The next reference and the load of the one after it are UNCONDITIONAL (the index clamped to the job's last
