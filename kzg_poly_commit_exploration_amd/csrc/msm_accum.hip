@@ -92,8 +92,10 @@ __device__ __forceinline__ void accum_issue_gather(const uint4* __restrict__ tab
                                          16, 0, 0);
 }
 // kFlushOps: vector-memory operations a bucket flush issues between the gather and this wait (accum_flush_run's sixteen
-// stores + the read of the next bucket's end).  The counter is in order: "at most kFlushOps outstanding" means the gather and
-// the reference load in front of them have landed, without waiting for a store's round trip to come back (+2 % at degree
+// stores + the read of the next bucket's end).  The counter is in order for global_* loads, stores and LDS-DMA alike
+// (MI355X_MICROARCH.md, "s_waitcnt vmcnt(N) waits until all but the wave's N youngest vector-memory operations are done"; only
+// flat_* is excepted, and there is none here): "at most kFlushOps outstanding" means the gather and the reference load in
+// front of them have landed, without waiting for a store's round trip to come back (+2 % at degree
 // 2^20, where one iteration in four of a wave has a lane at a bucket's end).  A SMALLER number of operations on that path
 // would make the wait too weak (the point would be read before it has arrived): tests/test_accum_isa.py counts them in
 // the compiler's output.  (The walk over empty buckets waits for everything inside its loop, so behind it the number is
