@@ -141,11 +141,10 @@ struct kzg_ctx {
     // the light sort / reduction kernels of the other slots run beside it on the slots' own streams.
     hipStream_t heavy_stream = nullptr;
     bool serialize_accum = true;   // KZG_SERIALIZE_ACCUM=0 lets accumulation kernels of different slots overlap
-    // LDS reserved per accumulation workgroup (KZG_ACCUM_LDS_KB overrides): 41 KB caps the kernel at three
-    // workgroups per CU whatever its register count.  The shipped build (lazily reduced field, 206 VGPRs) is
-    // register-limited to two workgroups per CU anyway, which leaves two wave slots and ~100 VGPRs per SIMD to
-    // the light kernels of the other slots (sort, quotient); the reservation only matters for builds under
-    // 170 VGPRs (a 168-VGPR build with 10 spilled registers measured 9 % slower with three slots in flight).
+    // LDS reserved per accumulation workgroup (KZG_ACCUM_LDS_KB overrides): 41 KB would cap the kernel at three workgroups
+    // per CU; its register count (176 reserved, msm_accum.hip) caps it at two, which is what its grid is launched for.
+    // Two workgroups leave 78 KB of LDS and 160 VGPRs per SIMD lane to the light kernels of the other slots (32 KB instead
+    // of 41 measured the same).
     uint32_t accum_lds_bytes = 41u * 1024u;
     uint32_t small_lds_bytes = 48u * 1024u;  // k_small_msm's LDS reservation (raised to small_msm_lds_bytes() at creation)
     bool small_msm_off = false;              // KZG_SMALL_MSM=0: small jobs take the general multi-launch path (A/B, tests)
